@@ -1,0 +1,305 @@
+"""Generates the golden fixtures in this directory by running the REAL reference
+(/root/reference, read-only) on CPU fp32.  Runs only in the build container — the GPU box
+has no /root/reference and never needs it: tests read the committed ``*.npz`` files.
+
+    python tests/golden/make_golden.py [case ...]      (no args = all cases)
+
+Nothing of the reference (source, bytecode, pickles) is written anywhere: fixtures hold
+only configs, seeds, and output numbers.  Parameters and inputs are regenerated in the
+tests from the seeds via oracle.dichavit_oracle.make_state / make_batch (numpy legacy
+RandomState: version-stable).
+
+Import shims: omegaconf and h5py are absent here and only touched at import
+time; ``models/__init__.py`` imports timm-based baselines, so ``models`` is pre-registered
+as a bare namespace package.
+"""
+import json
+import math
+import os
+import random
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import dichavit_oracle as orc  # noqa: E402
+
+REF = "/root/reference"
+
+
+def load_reference():
+    sys.path.insert(0, REF)
+    om = types.ModuleType("omegaconf"); om.MISSING = "???"; sys.modules["omegaconf"] = om
+    sys.modules["h5py"] = types.ModuleType("h5py")
+    pkg = types.ModuleType("models"); pkg.__path__ = [REF + "/models"]; sys.modules["models"] = pkg
+    import warnings
+    warnings.filterwarnings("ignore")
+    from models.dichavit import dichavit
+    from models import loss_fn
+    return dichavit, loss_fn
+
+
+class Cfg(dict):
+    __getattr__ = dict.get
+
+
+def base_cfg(**kw):
+    c = dict(name="dichavit", pretrained_model_name="small", patch_size=16, temperature=0.07, learnable_temp=False,
+             enable_sample=False, use_channelvit_channels=True, orthogonal_channel_emb_init=True,
+             dropout_tokens_hcs="none", freeze_channel_emb=False, block_type="block", hcs_sampling="none",
+             hcs_sampling_temp=0.1, proxy_loss_lambda=0.001, ortho_loss_v1_lambda=0.001, drop_path_rate=0.0,
+             gamma_s=1.0, gamma_d=4.0, reverse_pos_pairs=True, use_square=False, new_channel_inits=["zero"])
+    c.update(kw)
+    return c
+
+
+def build(dichavit, cfg, mapper, n_channels, img, num_classes, seed):
+    import contextlib, io
+    full = Cfg(cfg, in_channel_names=[f"c{i}" for i in range(n_channels)], img_size=[img], num_classes=num_classes)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = dichavit(full, mapper=mapper)
+    shapes = orc.state_shapes(cfg, n_channels, img, num_classes, chammi="Allen" in mapper)
+    st = orc.make_state(shapes, seed)
+    sd = m.state_dict()
+    want = set(sd.keys()) - {"adaptive_interface.0"}
+    assert want == set(st.keys()), (want ^ set(st.keys()))
+    for k, v in sd.items():
+        assert k == "adaptive_interface.0" or tuple(v.shape) == tuple(st[k].shape), k
+    missing = m.load_state_dict({**st, "adaptive_interface.0": st["proxies"]}, strict=True)
+    return m, sorted(sd.keys())
+
+
+def sample_idx(n, k=64):
+    return np.unique(np.linspace(0, n - 1, min(k, n)).astype(np.int64))
+
+
+def grad_summary(model):
+    out = {}
+    for name, p in model.named_parameters():
+        if name.startswith("adaptive_interface"):
+            continue
+        if p.grad is None:
+            out["gnone/" + name] = np.zeros(0)
+            continue
+        g = p.grad.detach().double().flatten().numpy()
+        out["gnorm/" + name] = np.array(np.linalg.norm(g))
+        out["gsamp/" + name] = g[sample_idx(g.size)].astype(np.float64)
+    return out
+
+
+def save(name, meta, arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path)/1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------------------
+def case_loss_fns(dichavit, loss_fn):
+    """Known answers for the two regularisers, straight from models/loss_fn.py (fp64)."""
+    arrays, meta = {}, {"cases": []}
+    B, C, n, D = 2, 3, 4, 8
+    i = torch.arange(B * C * n * D, dtype=torch.float64).reshape(B, C * n, D)
+    f = torch.sin(0.37 * i) + 0.25 * torch.cos((0.11 * i * i) % 7.0)
+    labels = torch.arange(C).repeat_interleave(n)
+    for k, (gs, gd, rev, sq) in enumerate([(1.0, 4.0, True, False), (0.5, 2.0, True, False),
+                                           (1.0, 0.5, False, False), (1.0, 4.0, True, True)]):
+        arrays[f"e1_{k}"] = np.array(loss_fn.ortho_proj_loss_fn_v2(f, labels, gs, gd, rev, sq).item())
+        meta["cases"].append(dict(kind="e1", k=k, gs=gs, gd=gd, rev=rev, sq=sq))
+    j = torch.arange(40, dtype=torch.float64).reshape(5, 8)
+    prox, emb, sc = torch.cos(0.3 * j), torch.sin(0.2 * j + 1.0), math.sqrt(1 / 0.07)
+    arrays["e2_eye"] = np.array(loss_fn.proxy_loss(prox, emb, torch.eye(5, dtype=torch.float64), sc).item())
+    arrays["e2_int"] = np.array(loss_fn.proxy_loss(prox, emb, torch.arange(5), sc).item())
+    # random features incl. gradient, several (C, n) incl. C == 1
+    rs = np.random.RandomState(7)
+    for k, (B, C, n, D, gs, gd, rev, sq) in enumerate([(2, 3, 16, 32, 1.0, 4.0, True, False),
+                                                      (3, 1, 9, 16, 0.5, 2.0, True, False),
+                                                      (2, 5, 4, 24, 1.0, 0.5, False, True),
+                                                      (1, 8, 49, 64, 1.0, 4.0, True, False)]):
+        feat = torch.from_numpy(rs.standard_normal((B, C * n, D))).requires_grad_(True)
+        labels = torch.arange(C).repeat_interleave(n)
+        val = loss_fn.ortho_proj_loss_fn_v2(feat, labels, gs, gd, rev, sq)
+        val.backward()
+        arrays[f"r_{k}_val"] = np.array(val.item())
+        arrays[f"r_{k}_grad"] = feat.grad.numpy()
+        arrays[f"r_{k}_feat"] = feat.detach().numpy()
+        meta["cases"].append(dict(kind="rand", k=k, B=B, C=C, n=n, D=D, gs=gs, gd=gd, rev=rev, sq=sq))
+    save("loss_fns", meta, arrays)
+
+
+def _train_case(dichavit, name, cfg, mapper, chunk, n_channels, C_in, img, K, B, seed, stages=True):
+    model, keys = build(dichavit, cfg, mapper, n_channels, img, K, seed)
+    model.train()
+    x, y = orc.make_batch(seed + 1, B, C_in, img, K)
+    arrays = {}
+    if stages:
+        fe = model.feature_extractor
+        with torch.no_grad():
+            tok, _ = fe.prepare_tokens(x, chunk, None, None, {})
+            arrays["tokens_row0"] = tok[0, : min(tok.shape[1], 40)].numpy()
+            arrays["tokens_last"] = tok[-1, -3:].numpy()
+            z = fe.blocks[0](tok)
+            arrays["block0_row0"] = z[0, : min(z.shape[1], 40)].numpy()
+    t = time.time()
+    out, extra = model(x, chunk, None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    main = torch.nn.CrossEntropyLoss()(out, y)
+    loss = main + 1.0 * extra
+    loss.backward()
+    print(f"  {name}: fwd+bwd {time.time()-t:.1f}s loss={loss.item():.6f} extra={extra.item():.6e}")
+    arrays.update(logits=out.detach().numpy(), extra=np.array(extra.item()), main=np.array(main.item()),
+                  loss=np.array(loss.item()))
+    arrays.update(grad_summary(model))
+    assert model.proxies.grad is None
+    meta = dict(cfg=cfg, mapper=mapper, chunk=chunk, n_channels=n_channels, C_in=C_in, img=img, num_classes=K, B=B,
+                seed=seed, state_keys=keys)
+    save(name, meta, arrays)
+
+
+def case_tiny(dichavit, loss_fn):
+    _train_case(dichavit, "tiny_e2e", base_cfg(pretrained_model_name="tiny", patch_size=8), {"train": [0, 1, 2]},
+                "train", 3, 3, 32, 5, 2, 11)
+
+
+def case_so2sat(dichavit, loss_fn):
+    """BASELINE config 1 shape: So2Sat S, 18ch 32x32 P8, 17 classes (train_scripts.sh:8 lambdas)."""
+    cfg = base_cfg(patch_size=8, ortho_loss_v1_lambda=0.1, gamma_s=0.5)
+    _train_case(dichavit, "so2sat_s", cfg, {"train": list(range(18))}, "train", 18, 18, 32, 17, 4, 21)
+
+
+def case_jumpcp(dichavit, loss_fn):
+    """BASELINE config 2 shape: JUMP-CP S, 8ch 224x224 P16, 161 classes, bs 2."""
+    _train_case(dichavit, "jumpcp_s", base_cfg(), {"train": list(range(8))}, "train", 8, 8, 224, 161, 2, 31)
+
+
+def case_hcs(dichavit, loss_fn):
+    """HCS sampling (dichavit.py:127-216): seeds recorded, resulting subset recorded."""
+    cfg = base_cfg(patch_size=8, enable_sample=True, hcs_sampling="lowest_cosine_prob", hcs_sampling_temp=0.1)
+    mapper = {"train": list(range(6))}
+    arrays, meta = {}, dict(cfg=cfg, mapper=mapper, n_channels=6, img=32, num_classes=7, B=3, seed=41, draws=[])
+    model, keys = build(dichavit, cfg, mapper, 6, 32, 7, 41)
+    model.train()
+    x, y = orc.make_batch(42, 3, 6, 32, 7)
+    for k, (pyseed, tseed, mode, temp) in enumerate([(1, 5, "lowest_cosine_prob", 0.1), (2, 6, "lowest_cosine_prob", 1000.0),
+                                                      (3, 7, "lowest_cosine", 0.1), (4, 8, "highest_cosine", 0.1),
+                                                      (5, 9, "none", 0.1), (9, 10, "lowest_cosine_prob", 0.01)]):
+        model.cfg["hcs_sampling"] = mode
+        model.cfg["hcs_sampling_temp"] = temp
+        pe = model.feature_extractor.patch_embed
+        pe.counter.clear()
+        random.seed(pyseed)
+        torch.manual_seed(tseed)
+        model.zero_grad()
+        out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+        loss.backward()
+        counter = dict(pe.counter)
+        # the sampled order is not exposed; recover it by replaying the documented draw order
+        rng = random.Random(pyseed)
+        torch.manual_seed(tseed)
+        picked, idx = orc.hcs_sample(pe.channel_embed.weight.detach(), mapper["train"], mode, temp, rng)
+        assert sorted(counter.keys()) == sorted(picked) or mode == "none", (counter, picked)
+        arrays[f"d{k}_logits"] = out.detach().numpy()
+        arrays[f"d{k}_extra"] = np.array(extra.item())
+        arrays[f"d{k}_loss"] = np.array(loss.item())
+        arrays[f"d{k}_picked"] = np.array(picked)
+        arrays[f"d{k}_gnorm_proj"] = np.array(pe.proj.weight.grad.norm().item())
+        arrays[f"d{k}_gnorm_chan"] = np.array(pe.channel_embed.weight.grad.norm().item())
+        arrays[f"d{k}_gchan"] = pe.channel_embed.weight.grad.numpy().copy()
+        meta["draws"].append(dict(pyseed=pyseed, tseed=tseed, mode=mode, temp=temp, counter={int(a): int(b) for a, b in counter.items()}))
+        print(f"  hcs draw {k}: mode={mode} picked={picked} loss={loss.item():.6f}")
+    save("hcs", meta, arrays)
+
+
+def case_chammi(dichavit, loss_fn):
+    """CHAMMI: 12-row channel_embed, non-identity mapper, features out, proxy main loss
+    (trainer.py:130-131, 912-914; dichavit.py:797-801).  3/4/5-channel chunks -> variable N."""
+    cfg = base_cfg(patch_size=16, proxy_loss_lambda=0.1, ortho_loss_v1_lambda=1.0, gamma_s=0.5, gamma_d=2.0)
+    mapper = {"Allen": [0, 1, 2], "HPA": [3, 4, 5, 6], "CP": [7, 8, 9, 10, 11]}
+    K, img, seed = 14, 64, 51
+    model, keys = build(dichavit, cfg, mapper, 12, img, K, seed)
+    model.train()
+    arrays = {}
+    scale = model.scale
+    for chunk in ["Allen", "HPA", "CP"]:
+        C = len(mapper[chunk])
+        x, y = orc.make_batch(seed + C, 2, C, img, K)
+        feat, extra = model(x, chunk, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = loss_fn.proxy_loss(model.proxies, feat, y, scale) + 1.0 * extra
+        loss.backward()  # grads accumulate over the three chunks, one optimizer step after (trainer.py:921-935)
+        arrays[f"{chunk}_feat"] = feat.detach().numpy()
+        arrays[f"{chunk}_extra"] = np.array(extra.item())
+        arrays[f"{chunk}_loss"] = np.array(loss.item())
+        print(f"  chammi {chunk}: loss={loss.item():.6f}")
+    arrays.update(grad_summary(model))
+    save("chammi", dict(cfg=cfg, mapper=mapper, n_channels=12, img=img, num_classes=K, B=2, seed=seed, state_keys=keys), arrays)
+
+
+def case_eval(dichavit, loss_fn):
+    """Eval path: bare tensor out; leave-one-out channel synthesis (dichavit.py:219-374)."""
+    cfg = base_cfg(patch_size=8)
+    mapper = {"train": [0, 1, 2, 3, 4], "test": [0, 1, 5, 3, 6], "valid": [0, 1, 2, 3, 4]}
+    model, keys = build(dichavit, cfg, mapper, 7, 32, 9, 61)
+    model.eval()
+    x, _ = orc.make_batch(62, 3, 5, 32, 9)
+    arrays = {}
+    with torch.inference_mode():
+        for init in ["zero", "avg_2", "avg_3", "replicate", "avg_2_not_in_chunk", "avg_3_not_in_chunk", "random"]:
+            out = model(x, "test", "train", init_first_layer=None, new_channel_init=init)
+            assert isinstance(out, torch.Tensor)
+            arrays["test_" + init] = out.numpy()
+        arrays["valid_none"] = model(x, "valid", None, init_first_layer=None, new_channel_init=None).numpy()
+    save("eval_newch", dict(cfg=cfg, mapper=mapper, n_channels=7, img=32, num_classes=9, B=3, seed=61), arrays)
+
+
+def _curve(dichavit, name, cfg, n_channels, img, K, B, seed, steps, n_batches, lr=4.9e-5, wd=0.04):
+    """`steps` training steps of trainer.train_one_batch_regular's body (trainer.py:963-1006):
+    zero_grad, forward, CE + extra, backward, AdamW step.  torch.optim.AdamW stands in for timm's
+    AdamW (same update rule); lr is the first-epoch warm-up value of the JUMP-CP
+    script: 1e-5 + (4e-4 - 1e-5)/10 (train_scripts.sh:5, configs/scheduler/cosine.yaml)."""
+    mapper = {"train": list(range(n_channels))}
+    model, keys = build(dichavit, cfg, mapper, n_channels, img, K, seed)
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=wd,
+                            betas=(0.9, 0.999), eps=1e-8)
+    batches = [orc.make_batch(seed + 100 + i, B, n_channels, img, K) for i in range(n_batches)]
+    losses = np.zeros((steps, 3))
+    t0 = time.time()
+    for s in range(steps):
+        x, y = batches[s % n_batches]
+        opt.zero_grad()
+        out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        main = torch.nn.CrossEntropyLoss()(out, y)
+        loss = main + 1.0 * extra
+        loss.backward()
+        opt.step()
+        losses[s] = (loss.item(), main.item(), extra.item())
+        if s % 10 == 0:
+            print(f"  {name} step {s}: loss={loss.item():.6f}  ({time.time()-t0:.0f}s)", flush=True)
+    save(name, dict(cfg=cfg, mapper=mapper, n_channels=n_channels, img=img, num_classes=K, B=B, seed=seed, steps=steps,
+                    n_batches=n_batches, lr=lr, wd=wd, betas=[0.9, 0.999], eps=1e-8), dict(losses=losses))
+
+
+def case_curve_so2sat(dichavit, loss_fn):
+    cfg = base_cfg(patch_size=8, ortho_loss_v1_lambda=0.1, gamma_s=0.5)
+    _curve(dichavit, "curve100_so2sat_s", cfg, 18, 32, 17, 8, 71, 100, 4)
+
+
+def case_curve_jumpcp(dichavit, loss_fn):
+    """headline architecture (S, 8ch 224x224 P16, 161 classes), bs 2, 100 steps — ~8 min on 8 cores."""
+    _curve(dichavit, "curve100_jumpcp_s", base_cfg(), 8, 224, 161, 2, 81, 100, 4)
+
+
+CASES = dict(loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
+             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp)
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    torch.manual_seed(0)
+    dichavit, loss_fn = load_reference()
+    for c in (sys.argv[1:] or list(CASES)):
+        print("case", c)
+        CASES[c](dichavit, loss_fn)
