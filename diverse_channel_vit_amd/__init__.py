@@ -1,0 +1,12 @@
+"""MI355X-native DiChaViT training hot path (gfx950 HIP kernels behind the reference's plugin surface).
+
+    from diverse_channel_vit_amd import dichavit          # == models.dichavit of the reference
+    model = dichavit(cfg.model, mapper=mapper).to("cuda")
+
+See DESIGN.md / INTEGRATION.md.  Importing this package never touches the GPU and never falls back to
+a CPU implementation: the first forward loads diverse_channel_vit_amd/libdcv_hip.so or raises."""
+from .dichavit import DiChaViT, dichavit, proxy_loss  # noqa: F401
+from .dp import DataParallel  # noqa: F401
+from .optim import HipAdamW  # noqa: F401
+
+__all__ = ["DiChaViT", "dichavit", "proxy_loss", "DataParallel", "HipAdamW"]

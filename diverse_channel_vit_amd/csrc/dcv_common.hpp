@@ -1,0 +1,136 @@
+// Shared device helpers for the gfx950 (CDNA4 / MI355X) kernels of libdcv_hip.so.
+// wave = 64 lanes; MFMA bf16 32x32x16; LDS tiles are XOR-swizzled so that the same image
+// serves ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#include "../../include/dcv.h"
+
+#define DCV_LAUNCH_CHECK()                                   \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return DCV_ERR_LAUNCH;        \
+    } while (0)
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+union U128 {
+    uint4 u;
+    bf16x8 h;
+    bf16x4 q[2];
+    uint2 d[2];
+};
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) {
+    U128 x;
+    x.u = v;
+    return x.h;
+}
+__device__ __forceinline__ uint4 as_uint4(bf16x8 v) {
+    U128 x;
+    x.h = v;
+    return x.u;
+}
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// 32x32 accumulator: register r of lane l holds row acc_row(r, l>>5), column l&31.
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// pack registers 8s..8s+7 of a 32x32 f32 accumulator into the bf16 operand fragment of k-step s
+// of a following 32x32x16 MFMA that sums over the accumulator's ROW index.  The k order inside the
+// step is permuted: element j of lane half h is accumulator row 16s + 8(j>>2) + 4h + (j&3).
+__device__ __forceinline__ bf16x8 acc_to_frag(const f32x16& x, int s) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)x[8 * s + j];
+    return r;
+}
+
+// ---- 64-column bf16 LDS tile (128-byte rows, 8 chunks of 16 B) ------------------------------
+// chunk' = chunk ^ f(row), f(row) = k ^ ((k & 1) << 2), k = (row >> 1) & 7.
+//  * ds_read_b128 row reads (lane = row, same chunk): 16 rows of a lane group hit 16 distinct
+//    16-B slots of the 256-B bank row -> conflict-free.
+//  * ds_read_b64_tr_b16 (4 rows x 64 B per 32-lane half): rows q and q+2 land in different 64-B
+//    halves -> conflict-free.
+__device__ __forceinline__ int swz64(int row) {
+    int k = (row >> 1) & 7;
+    return k ^ ((k & 1) << 2);
+}
+// byte offset of element (row, col) in a [rows][64] bf16 tile
+__device__ __forceinline__ int lds64_off(int row, int col) {
+    return row * 128 + ((((col >> 3) ^ swz64(row)) << 4) | ((col & 7) << 1));
+}
+
+// ---- 128-column bf16 LDS tile (256-byte rows, 16 chunks) for transposed reads only ----------
+// 64-B segment index (4 per row) is XORed with (row & 3): the 4 rows of a tr read go to 4
+// different segments of the bank row.
+__device__ __forceinline__ int lds128_off(int row, int col) {
+    int chunk = (col >> 3) ^ ((row & 3) << 2);
+    return row * 256 + ((chunk << 4) | ((col & 7) << 1));
+}
+
+// transposed read: a 16-lane group reads a 4-row x 16-column block; lane i of the group passes
+// the address of (row i>>2, cols 4*(i&3)..+3) and receives column i, rows 0..3.
+__device__ __forceinline__ bf16x4 lds_tr_read(const char* base_generic, int byte_off) {
+    s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, base_generic + byte_off));
+    union {
+        s16x4 s;
+        bf16x4 b;
+    } u;
+    u.s = t;
+    return u.b;
+}
+
+__device__ __forceinline__ bf16x8 join4(bf16x4 lo, bf16x4 hi) {
+    U128 x;
+    x.q[0] = lo;
+    x.q[1] = hi;
+    return x.h;
+}
+
+__device__ __forceinline__ uint4 lds_read128(const char* base, int byte_off) {
+    return *reinterpret_cast<const uint4*>(base + byte_off);
+}
+__device__ __forceinline__ void lds_write128(char* base, int byte_off, uint4 v) {
+    *reinterpret_cast<uint4*>(base + byte_off) = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) {
+    union {
+        bf16x4 v;
+        uint2 u;
+    } x;
+    x.v[0] = (bf16_t)a;
+    x.v[1] = (bf16_t)b;
+    x.v[2] = (bf16_t)c;
+    x.v[3] = (bf16_t)d;
+    return x.u;
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch, speed only).  Gives each
+// XCD a contiguous range of logical ids.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    int q = n >> 3, r = n & 7;
+    int xcd = bid & 7, slot = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}

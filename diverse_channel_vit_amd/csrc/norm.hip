@@ -1,0 +1,173 @@
+// LayerNorm forward / backward over the fp32 residual stream (HBM-bound, one wave per token row).
+// Replaces nn.LayerNorm(eps=1e-6) in Block.forward (models/vit.py:361,374,384,398) and the final
+// norm (models/dichavit.py:651).
+//   fwd : x f32 [M,D] -> u bf16 [M,D] (the GEMM A operand, kept for backward), mean/rstd f32 [M]
+//   bwd : dx_out = dx_in + LN'(du)  (residual add fused), bf16 copy of dx_out for the next GEMMs,
+//         dgamma/dbeta accumulated per workgroup then one atomic per column.
+#include "dcv_common.hpp"
+#include "../../include/dcv.h"
+
+namespace {
+
+constexpr int MAXV = 4;  // float4 per lane: D <= 64*4*4 = 1024
+
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, void* __restrict__ u,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                     float eps, long x_row_stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;  // float4 per row
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_row_stride);
+        float4 v[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + 64 * i;
+            v[i] = (c < nv) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+        const float mu = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + 64 * i;
+            if (c < nv) {
+                float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+                q += a * a + b * b + cc * cc + d * d;
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / D + eps);
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + 64 * i;
+            if (c < nv) {
+                const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+                const float4 bb = reinterpret_cast<const float4*>(beta)[c];
+                float o0 = (v[i].x - mu) * rs * g.x + bb.x, o1 = (v[i].y - mu) * rs * g.y + bb.y;
+                float o2 = (v[i].z - mu) * rs * g.z + bb.z, o3 = (v[i].w - mu) * rs * g.w + bb.w;
+                if constexpr (OUT_F32)
+                    reinterpret_cast<float4*>((float*)u + (size_t)row * D)[c] = make_float4(o0, o1, o2, o3);
+                else
+                    reinterpret_cast<uint2*>((bf16_t*)u + (size_t)row * D)[c] = pack4_bf16(o0, o1, o2, o3);
+            }
+        }
+    }
+}
+
+template <bool DU_F32>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* dx_in, float* dx_out,
+                                                     bf16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int D, long x_row_stride,
+                                                     long dx_row_stride) {
+    __shared__ float red[4][2][MAXV * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = D >> 2;
+    float4 ag[MAXV], ab[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_row_stride);
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[MAXV], g[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + 64 * i;
+            xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nv) {
+                float4 xv = xr[c];
+                float4 d;
+                if constexpr (DU_F32) {
+                    d = reinterpret_cast<const float4*>((const float*)du + (size_t)row * D)[c];
+                } else {
+                    uint2 raw = reinterpret_cast<const uint2*>((const bf16_t*)du + (size_t)row * D)[c];
+                    d = make_float4(bf16_bits_to_f32(raw.x & 0xffff), bf16_bits_to_f32(raw.x >> 16),
+                                    bf16_bits_to_f32(raw.y & 0xffff), bf16_bits_to_f32(raw.y >> 16));
+                }
+                const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+                s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+                s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+                ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+                ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+            }
+        }
+        const float m1 = wave_sum(s1) / D, m2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + 64 * i;
+            if (c < nv) {
+                float4 r = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2),
+                                       rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2));
+                if (dx_in) {
+                    float4 p = reinterpret_cast<const float4*>(dx_in + (size_t)row * dx_row_stride)[c];
+                    r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w;
+                }
+                reinterpret_cast<float4*>(dx_out + (size_t)row * dx_row_stride)[c] = r;
+                if (dx_bf16) reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * D)[c] = pack4_bf16(r.x, r.y, r.z, r.w);
+            }
+        }
+    }
+    // column reduction across the 4 waves, then one atomic per column per workgroup
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        reinterpret_cast<float4*>(red[wave][0])[lane + 64 * i] = ag[i];
+        reinterpret_cast<float4*>(red[wave][1])[lane + 64 * i] = ab[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        int v4 = c >> 2, e = c & 3;
+        int slot = v4 * 4 + e;  // float index inside the [MAXV*64] float4 array
+        float sg = 0.f, sb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            sg += red[w][0][slot];
+            sb += red[w][1][slot];
+        }
+        atomicAdd(dgamma + c, sg);
+        atomicAdd(dbeta + c, sb);
+    }
+}
+
+}  // namespace
+
+extern "C" int dcv_ln_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, void* out, int out_is_f32,
+                          float* mean, float* rstd, int M, int D, float eps, void* stream) {
+    if (!x || !gamma || !beta || !out) return DCV_ERR_NULL;
+    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAXV || (x_row_stride & 3)) return DCV_ERR_SHAPE;
+    int grid = (M + 3) / 4;
+    if (grid > 4096) grid = 4096;
+    if (out_is_f32)
+        hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_ln_bwd(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
+                          const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
+                          float* dbeta, int M, int D, void* stream) {
+    if (!du || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta) return DCV_ERR_NULL;
+    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAXV || (x_row_stride & 3) || (dx_row_stride & 3)) return DCV_ERR_SHAPE;
+    int grid = (M + 3) / 4;
+    if (grid > 1024) grid = 1024;
+    if (du_is_f32)
+        hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, du, x, mean, rstd, gamma, dx_in, dx_out,
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, du, x, mean, rstd, gamma, dx_in, dx_out,
+                           (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}

@@ -1,0 +1,145 @@
+// Parameter-arena kernels: fused AdamW over the flat fp32 arena, and the bf16 operand copies of the
+// weights (straight and transposed) that the MFMA GEMMs read.
+// AdamW restates timm/torch decoupled-weight-decay Adam (optimizers.py:20-21, trainer.py:1006):
+//   p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+#include "dcv_common.hpp"
+#include "../../include/dcv.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n4, long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float inv_bc1, float inv_sqrt_bc2, float gscale) {
+    const long stride = (long)gridDim.x * 256;
+    const float decay = 1.f - lr * wd, step = lr * inv_bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+        float4 Mv = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        float* pp = &P.x; float* gg = &G.x; float* mm = &Mv.x; float* vv = &V.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float gr = gg[e] * gscale;
+            float pe = pp[e] * decay;
+            mm[e] = b1 * mm[e] + (1.f - b1) * gr;
+            vv[e] = b2 * vv[e] + (1.f - b2) * gr * gr;
+            pp[e] = pe - step * mm[e] / (sqrtf(vv[e]) * inv_sqrt_bc2 + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = P;
+        reinterpret_cast<float4*>(m)[i] = Mv;
+        reinterpret_cast<float4*>(v)[i] = V;
+    }
+    // scalar tail
+    if (blockIdx.x == 0) {
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            float gr = g[i] * gscale;
+            float pe = p[i] * decay;
+            float me = b1 * m[i] + (1.f - b1) * gr;
+            float ve = b2 * v[i] + (1.f - b2) * gr * gr;
+            m[i] = me;
+            v[i] = ve;
+            p[i] = pe - step * me / (sqrtf(ve) * inv_sqrt_bc2 + eps);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(src)[i];
+        reinterpret_cast<uint2*>(dst)[i] = pack4_bf16(v.x, v.y, v.z, v.w);
+    }
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) dst[i] = (bf16_t)src[i];
+}
+
+// desc[k] = {src offset (floats), dst offset (bf16 elems), R, C}: dst[C][R] = bf16(src[R][C])
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             const long long* __restrict__ desc) {
+    __shared__ float tile[64][65];
+    const long long* d = desc + 4 * blockIdx.y;
+    const long long so = d[0], doff = d[1];
+    const int R = (int)d[2], C = (int)d[3];
+    const int tr = (R + 63) / 64, tc = (C + 63) / 64;
+    if ((int)blockIdx.x >= tr * tc) return;
+    const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int rr = ty; rr < 64; rr += 4) {
+        int r = r0 + rr, c = c0 + tx;
+        tile[rr][tx] = (r < R && c < C) ? src[so + (long long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int cc = ty; cc < 64; cc += 4) {
+        int c = c0 + cc, r = r0 + tx;
+        if (c < C && r < R) dst[doff + (long long)c * R + r] = (bf16_t)tile[tx][cc];
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_cls_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos0, int B, long batch_stride, int D) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * D) return;
+    int b = i / D, d = i % D;
+    x[(size_t)b * batch_stride + d] = cls[d] + pos0[d];
+}
+
+}  // namespace
+
+extern "C" int dcv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v) return DCV_ERR_NULL;
+    if (n <= 0 || step <= 0) return DCV_ERR_SHAPE;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return DCV_ERR_ALIGN;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    long n4 = n / 4;
+    long grid = (n4 + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, beta1, beta2, eps,
+                       weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_cast_bf16(const float* src, void* dst, long n, void* stream) {
+    if (!src || !dst) return DCV_ERR_NULL;
+    if (n <= 0) return DCV_ERR_SHAPE;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return DCV_ERR_ALIGN;
+    long n4 = n / 4;
+    long grid = (n4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4, n);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_cast_transpose_bf16(const float* src_base, void* dst_base, const long long* desc_dev, int n_desc, int max_tiles,
+                                       void* stream) {
+    if (!src_base || !dst_base || !desc_dev) return DCV_ERR_NULL;
+    if (n_desc <= 0 || max_tiles <= 0) return DCV_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(max_tiles, n_desc), dim3(256), 0, (hipStream_t)stream, src_base, (bf16_t*)dst_base, desc_dev);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_fill_cls(float* x, const float* cls, const float* pos0, int B, long batch_stride, int D, void* stream) {
+    if (!x || !cls || !pos0) return DCV_ERR_NULL;
+    if (B <= 0 || D <= 0) return DCV_ERR_SHAPE;
+    hipLaunchKernelGGL(fill_cls_kernel, dim3((B * D + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, cls, pos0, B, batch_stride, D);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_version(void) { return 100; }
+
+extern "C" const char* dcv_error_string(int code) {
+    switch (code) {
+        case DCV_OK: return "ok";
+        case DCV_ERR_SHAPE: return "bad shape";
+        case DCV_ERR_ALIGN: return "bad alignment / leading dimension";
+        case DCV_ERR_UNSUPPORTED: return "unsupported configuration (e.g. head_dim != 64)";
+        case DCV_ERR_LAUNCH: return "HIP launch failed";
+        case DCV_ERR_NULL: return "null pointer";
+        default: return "unknown error";
+    }
+}

@@ -1,0 +1,657 @@
+"""Host-side mirror of the reference's DiChaViT plugin (models/dichavit.py:748-865) whose compute runs
+entirely in libdcv_hip.so on an MI355X.
+
+Drop-in contract kept: factory ``dichavit(cfg, mapper=...)``, class ``DiChaViT`` with
+``forward(x, chunk_name, training_chunks=None, init_first_layer=None, new_channel_init=None, **kw)``
+returning ``(out, extra_loss)`` in training and ``out`` in eval, the attributes the trainer touches
+(``proxies``, ``scale``/``logit_scale``, ``feature_extractor.patch_embed.{counter,mapper}``) and the
+reference's state_dict keys/shapes (checkpoints load both ways).
+
+Design (MI355X-first, not a translation):
+  * all parameters live in ONE flat fp32 arena (views are the nn.Parameters); bf16 operand copies
+    (straight + transposed) are refreshed with two launches per forward; gradients of the encoder
+    are produced into ONE flat fp32 arena (atomics from the split-M weight-gradient GEMMs), so data
+    parallel all-reduce and the fused AdamW each see a single contiguous range.
+  * the whole tokeniser + 12-block encoder is one autograd node with a hand-written backward that
+    calls the HIP kernels; activations are bf16, the residual stream, LayerNorm/softmax statistics and
+    all accumulations are fp32.  The N x N attention matrix and the T x T cosine matrix of the
+    diversity loss are never materialised.
+  * there is NO CPU or eager fallback: tensors must be on the GPU and the library must be present.
+"""
+from __future__ import annotations
+
+import math
+import random
+from collections import Counter, defaultdict
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip
+
+LN_EPS = 1e-6  # models/dichavit.py:688,706,724,742
+_SIZES = {"tiny": (192, 12, 3), "small": (384, 12, 6), "base": (768, 12, 12), "distill": (384, 12, 6)}  # :676-745
+_NEW_CHANNEL_INITS = ("avg_2", "avg_2_not_in_chunk", "avg_3", "avg_3_not_in_chunk", "replicate", "zero", "random")
+
+
+def _cfg_get(cfg, key, default=None):
+    """cfg is a DictConfig-like node: attribute access and .get() both work (dichavit.py:63)."""
+    if hasattr(cfg, "get"):
+        v = cfg.get(key, default)
+        return default if v is None and default is not None else v
+    return getattr(cfg, key, default)
+
+
+# ------------------------------------------------------------------------------------------------
+# positional-embedding resample (interpolate_pos_encoding, dichavit.py:518-552)
+# ------------------------------------------------------------------------------------------------
+def _bicubic_matrix_1d(g_in: int, g_out: int, scale: float) -> torch.Tensor:
+    """1-D matrix of F.interpolate(mode='bicubic', align_corners=False) with an explicit scale_factor:
+    src = (dst + 0.5)/scale - 0.5, Keys kernel A = -0.75, index-clamped taps."""
+    A = -0.75
+    R = torch.zeros(g_out, g_in, dtype=torch.float64)
+    for o in range(g_out):
+        f = (o + 0.5) / scale - 0.5
+        i0 = math.floor(f)
+        t = f - i0
+        w = [((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A,
+             ((A + 2) * t - (A + 3)) * t * t + 1,
+             ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1,
+             ((A * (2 - t) - 5 * A) * (2 - t) + 8 * A) * (2 - t) - 4 * A]
+        for k in range(4):
+            R[o, min(max(i0 - 1 + k, 0), g_in - 1)] += w[k]
+    return R
+
+
+class _PosResample(torch.autograd.Function):
+    """out = Ry . grid . Rx^T per feature.  The backward mirrors ATen: when the output grid has the
+    input's size, upsample_bicubic2d_backward takes its 'same size: copy' early-out, i.e. the gradient
+    passes straight through although the forward resampled (observed with the reference here;
+    DESIGN.md 'parity traps')."""
+
+    @staticmethod
+    def forward(ctx, grid, Ry, Rx):
+        ctx.save_for_backward(Ry, Rx)
+        ctx.same = Ry.shape[0] == Ry.shape[1] and Rx.shape[0] == Rx.shape[1]
+        return torch.einsum("oy,px,yxd->opd", Ry, Rx, grid)
+
+    @staticmethod
+    def backward(ctx, g):
+        Ry, Rx = ctx.saved_tensors
+        if ctx.same:
+            return g, None, None
+        return torch.einsum("oy,px,opd->yxd", Ry, Rx, g), None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names = the reference's state_dict keys)
+# ------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container of the HIP path; call DiChaViT.forward")
+
+
+class Attention(_Holder):  # models/vit.py:101-119
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(_Holder):  # models/vit.py:59-74
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class Block(_Holder):  # models/vit.py:346-381
+    def __init__(self, dim, mlp_ratio=4.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=LN_EPS)
+        self.attn = Attention(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=LN_EPS)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+class PatchEmbedPerChannel(_Holder):
+    """models/dichavit.py:39-96 — parameters, mapper and the HCS pick histogram."""
+
+    def __init__(self, cfg, img_size, patch_size, in_chans, mapper, embed_dim, enable_sample, use_channelvit_channels):
+        super().__init__()
+        self.cfg = cfg
+        self.img_size = img_size
+        self.mapper = mapper
+        self.patch_size = patch_size
+        self.num_patches = (img_size // patch_size) * (img_size // patch_size) * in_chans
+        self.channel_scale = np.sqrt(1.0 / cfg.temperature)
+        if _cfg_get(cfg, "proxy_loss_lambda", 0) > 0:
+            self.channel_emb_proxies = nn.Parameter(torch.randn(in_chans, embed_dim) / 8)
+            if _cfg_get(cfg, "proxy_orthogonal_init", False):
+                nn.init.orthogonal_(self.channel_emb_proxies)
+        hcs = _cfg_get(cfg, "hcs_sampling", "none")
+        if hcs != "none" and hcs is not None:
+            self.counter = defaultdict(lambda: 0)
+            if str(hcs).endswith("resnet34"):
+                raise ValueError("hcs_sampling=*_resnet34 needs a pretrained timm download; not available (SURVEY §8a a8)")
+        self.proj = nn.Conv3d(1, embed_dim, kernel_size=(1, patch_size, patch_size), stride=(1, patch_size, patch_size))
+        if use_channelvit_channels:
+            self.channel_embed = nn.Embedding(in_chans, embed_dim)
+            if _cfg_get(cfg, "orthogonal_channel_emb_init", False):
+                nn.init.orthogonal_(self.channel_embed.weight)
+            else:
+                nn.init.trunc_normal_(self.channel_embed.weight, std=0.02, a=-2.0, b=2.0)
+            if _cfg_get(cfg, "freeze_channel_emb", False):
+                self.channel_embed.weight.requires_grad = False
+        else:
+            raise ValueError("use_channelvit_channels=False is not supported by the HIP path")
+        self.use_channelvit_channels = use_channelvit_channels
+        self.enable_sample = enable_sample
+
+
+class ChannelVisionTransformer(_Holder):
+    """models/dichavit.py:420-516 — parameter layout and initialisation."""
+
+    def __init__(self, cfg, img_size, patch_size, in_chans, mapper, embed_dim, depth, num_heads, enable_sample,
+                 use_channelvit_channels):
+        super().__init__()
+        self.cfg = cfg
+        if _cfg_get(cfg, "block_type", "block") != "block":
+            if cfg.block_type == "block_v2":
+                raise ValueError("block_type=block_v2 is experimental in the reference (SURVEY §2.1 #2) and not provided")
+            raise ValueError(f"Unknown block type: {cfg.block_type}")
+        if (_cfg_get(cfg, "drop_path_rate", 0.0) or 0.0) != 0.0:
+            raise ValueError("drop_path_rate > 0 is not supported by the HIP path (all reference scripts use 0)")
+        self.num_features = self.embed_dim = self.out_dim = embed_dim
+        self.in_chans = in_chans
+        self.num_heads = num_heads
+        self.patch_embed = PatchEmbedPerChannel(cfg, img_size[0], patch_size, in_chans, mapper, embed_dim, enable_sample,
+                                                use_channelvit_channels)
+        self.patch_size = patch_size
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.num_extra_tokens = 1
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_embed.num_patches // in_chans + 1, embed_dim))
+        self.blocks = nn.ModuleList([Block(embed_dim) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=LN_EPS)
+        self.head = nn.Identity()
+        nn.init.trunc_normal_(self.pos_embed, std=0.02, a=-2.0, b=2.0)
+        nn.init.trunc_normal_(self.cls_token, std=0.02, a=-2.0, b=2.0)
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):  # dichavit.py:509-516
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02, a=-2.0, b=2.0)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# the single autograd node: tokeniser + encoder on HIP kernels
+# ------------------------------------------------------------------------------------------------
+class _EncoderFn(torch.autograd.Function):
+    """inputs : x [B,Ct,H,W] f32, E [C,D] f32 (channel-embedding rows of this step), pos_tab [1+n,D] f32,
+                then the encoder parameters in arena order (model._enc_params).
+       outputs: CLS feature after the final LayerNorm [B,D] f32, ortho statistics [B,2] f32."""
+
+    @staticmethod
+    def forward(ctx, model, ch_idx_dev, C, want_ortho, x, E, pos_tab, *params):
+        st = model._run_forward(x, ch_idx_dev, C, E, pos_tab, want_ortho, save=any(ctx.needs_input_grad))
+        ctx.model = model
+        ctx.st = st
+        return st["feat"], st["stats"]
+
+    @staticmethod
+    def backward(ctx, dfeat, dstats):
+        model, st = ctx.model, ctx.st
+        ctx.st = None
+        if st.get("consumed"):
+            raise RuntimeError("the HIP encoder node frees its activations in backward; backward twice is not supported")
+        dE, dpos, grads = model._run_backward(st, dfeat.contiguous(), dstats)
+        st["consumed"] = True
+        st.clear()
+        return (None, None, None, None, None, dE, dpos) + tuple(grads)
+
+
+class DiChaViT(nn.Module):
+    def __init__(self, config, **kwargs):
+        super().__init__()
+        self.cfg = config
+        mapper = kwargs["mapper"]
+        total_in_channels = len(config.in_channel_names)
+        name = config.pretrained_model_name
+        if name not in _SIZES:
+            raise ValueError("Unknown model name")  # dichavit.py:794
+        D, depth, heads = _SIZES[name]
+        self.feature_extractor = ChannelVisionTransformer(
+            config, config.img_size, config.patch_size, total_in_channels, mapper, D, depth, heads,
+            config.enable_sample, config.use_channelvit_channels)
+        self.classifer_head = nn.Identity()
+        if "Allen" not in mapper:  # dichavit.py:799-801
+            self.classifer_head = nn.Linear(D, config.num_classes)
+        self.dim = D
+        self.proxies = nn.Parameter(torch.randn(config.num_classes, D) / 8)  # :803-805
+        if _cfg_get(config, "learnable_temp", False):
+            self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / config.temperature))
+        else:
+            self.scale = np.sqrt(1.0 / config.temperature)
+        self.adaptive_interface = nn.ParameterList([self.proxies])  # :812 (state_dict alias key)
+        # --- HIP-path state (not part of the state_dict) ---
+        self._arena = None
+        self._grad_arena = None
+        self._dp = None  # set by diverse_channel_vit_amd.dp.DataParallel
+        self._R_cache: Dict = {}
+        self.hcs_sampler = None  # optional callable(model, chunk_name, cur_channels) -> (picked ids, positions): pins the subset
+
+    # ---------------------------------------------------------------------------------------
+    # arena management
+    # ---------------------------------------------------------------------------------------
+    def _enc_param_list(self) -> List[nn.Parameter]:
+        fe = self.feature_extractor
+        ps = [fe.cls_token, fe.patch_embed.proj.weight, fe.patch_embed.proj.bias]
+        for b in fe.blocks:
+            ps += [b.norm1.weight, b.norm1.bias, b.attn.qkv.weight, b.attn.qkv.bias, b.attn.proj.weight, b.attn.proj.bias,
+                   b.norm2.weight, b.norm2.bias, b.mlp.fc1.weight, b.mlp.fc1.bias, b.mlp.fc2.weight, b.mlp.fc2.bias]
+        ps += [fe.norm.weight, fe.norm.bias]
+        return ps
+
+    def _ensure_arena(self, device):
+        enc = self._enc_param_list()
+        a = self._arena
+        if a is not None and a.device == device and enc[0].data_ptr() == a.data_ptr() and \
+                enc[-1].data_ptr() == a.data_ptr() + self._enc_off[-1] * 4:
+            return
+        # (re)build: encoder parameters first (16-byte aligned slots), then every other parameter
+        seen, others = {id(p) for p in enc}, []
+        for p in self.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                others.append(p)
+        offs, off = [], 0
+        for p in enc + others:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        arena = torch.zeros(off, dtype=torch.float32, device=device)
+        for p, o in zip(enc + others, offs):
+            view = arena[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = view
+        self._arena = arena
+        self._all_params = enc + others
+        self._all_off = offs
+        self._enc_params = enc
+        self._enc_off = offs[:len(enc)]
+        self._enc_size = offs[len(enc)] if others else off
+        self._grad_arena = None
+        self._bf16 = torch.empty(self._enc_size, dtype=torch.bfloat16, device=device)    # same offsets as the arena
+        self._bf16_t = torch.empty(self._enc_size, dtype=torch.bfloat16, device=device)  # transposed copies of matrices
+        # transposed copies are needed for the four Linear weights of every block (input-gradient GEMMs)
+        desc, max_tiles = [], 1
+        self._w_index = {}
+        for i, p in enumerate(enc):
+            self._w_index[id(p)] = i
+        for b in self.feature_extractor.blocks:
+            for w in (b.attn.qkv.weight, b.attn.proj.weight, b.mlp.fc1.weight, b.mlp.fc2.weight):
+                o = self._enc_off[self._w_index[id(w)]]
+                R, Cc = w.shape
+                desc.append([o, o, R, Cc])
+                max_tiles = max(max_tiles, ((R + 63) // 64) * ((Cc + 63) // 64))
+        self._tdesc = torch.tensor(desc, dtype=torch.int64, device=device)
+        self._tdesc_n, self._tdesc_tiles = len(desc), max_tiles
+
+    def _bf(self, p, transposed=False):
+        o = self._enc_off[self._w_index[id(p)]]
+        buf = self._bf16_t if transposed else self._bf16
+        v = buf[o:o + p.numel()]
+        if p.dim() >= 2:
+            R = p.shape[0]
+            return v.view(p.numel() // R, R) if transposed else v.view(R, p.numel() // R)
+        return v
+
+    def _refresh_operand_copies(self):
+        hip.cast_bf16(self._arena, self._bf16, self._enc_size)
+        hip.cast_transpose_bf16(self._arena, self._bf16_t, self._tdesc, self._tdesc_n, self._tdesc_tiles)
+
+    def _new_grad_arena(self):
+        """A zeroed flat gradient buffer for the encoder parameters.  The previous one is reused when no
+        parameter's .grad still aliases it (optimizer.zero_grad(set_to_none=True) flow)."""
+        ga = self._grad_arena
+        if ga is not None:
+            busy = any(p.grad is not None and p.grad.untyped_storage().data_ptr() == ga.untyped_storage().data_ptr()
+                       for p in (self._enc_params[0], self._enc_params[2], self._enc_params[-1]))
+            if not busy:
+                ga.zero_()
+                return ga
+        ga = torch.zeros(self._enc_size, dtype=torch.float32, device=self._arena.device)
+        self._grad_arena = ga
+        return ga
+
+    # ---------------------------------------------------------------------------------------
+    # host-side pieces of PatchEmbedPerChannel.forward (dichavit.py:110-417)
+    # ---------------------------------------------------------------------------------------
+    def _sample_channels(self, chunk_name, cur_channels, channel_embed):
+        """HCS sampling (dichavit.py:127-216).  Returns (sampled global ids, their positions in the chunk)."""
+        pe = self.feature_extractor.patch_embed
+        cfg = self.cfg
+        if self.hcs_sampler is not None:
+            picked, idx = self.hcs_sampler(self, chunk_name, list(cur_channels))
+        else:
+            Cin = len(cur_channels)
+            Cin_new = random.randint(1, Cin)  # :128
+            mode = _cfg_get(cfg, "hcs_sampling", "none")
+            if mode == "none" or mode is None:
+                picked = random.sample(list(cur_channels), k=Cin_new)  # :131
+                idx = [list(cur_channels).index(c) for c in picked]
+                return picked, idx  # the reference does not count picks in this mode
+            if mode == "hcs_per_sample":
+                raise ValueError("hcs_per_sample not implemented!")  # :394-395
+            with torch.no_grad():
+                anchor = random.randint(0, Cin - 1)  # :154
+                if mode.endswith("_proj"):
+                    raise ValueError(f"hcs_sampling='{mode}' (projection-space cosine) is not provided by the HIP path")
+                e = F.normalize(channel_embed.detach(), p=2, dim=-1)
+                cos = (e @ e.t())[anchor]  # :169-174
+                if mode == "lowest_cosine":
+                    ind = torch.topk(cos, k=Cin_new, largest=False).indices.cpu().tolist()
+                elif mode == "highest_cosine":
+                    ind = torch.topk(cos, k=Cin_new, largest=True).indices.cpu().tolist()
+                elif mode == "lowest_cosine_prob":
+                    prob = F.softmax((1 - cos) / cfg.hcs_sampling_temp, dim=-1)  # :194-196
+                    ind = torch.multinomial(prob, Cin_new, replacement=False).cpu().tolist()  # :199
+                else:
+                    raise ValueError(f"Invalid hcs_sampling: '{mode}'")  # :206
+                if anchor not in ind:  # :201-202
+                    ind[-1] = anchor
+            picked = [cur_channels[i] for i in ind]
+            idx = [list(cur_channels).index(c) for c in picked]
+        if hasattr(pe, "counter"):
+            for k, v in Counter(picked).items():  # :214-216
+                pe.counter[k] += v
+        return picked, idx
+
+    def _eval_channel_embed(self, chunk_name, training_chunks, new_channel_init):
+        """Leave-one-out channel embeddings at eval time (dichavit.py:219-374; static variants)."""
+        pe = self.feature_extractor.patch_embed
+        W = pe.channel_embed.weight
+        mapper = pe.mapper
+        train_ch = [c for ch in training_chunks.split("_") for c in mapper[ch]]
+        not_seen = [c for c in train_ch if c not in mapper[chunk_name]]
+        init = str(new_channel_init.value) if hasattr(new_channel_init, "value") else new_channel_init
+        bank = not_seen if (init is not None and "not_in_chunk" in init) else train_ch
+        rows, cur = [], 0
+        for c in mapper[chunk_name]:
+            if c in train_ch:
+                rows.append(W[c][None])
+                continue
+            if init in ("avg_2", "avg_2_not_in_chunk"):
+                r = W[[bank[cur], bank[(cur + 1) % len(bank)]]].mean(0, keepdim=True)
+            elif init in ("avg_3", "avg_3_not_in_chunk"):
+                r = W[[bank[cur], bank[(cur + 1) % len(bank)], bank[(cur + 2) % len(bank)]]].mean(0, keepdim=True)
+            elif init == "replicate":
+                r = W[bank[cur]][None]
+            elif init == "zero":
+                r = torch.zeros_like(W[0])[None]
+            elif init == "random":
+                r = W[c][None]
+            elif init is not None and ("dynamic_input_corr" in init or init in ("fixed_input_corr", "random_input_corr")):
+                raise ValueError(f"new_channel_init='{init}' needs a channel bank/map nobody sets in the reference (SURVEY §8a a9)")
+            else:
+                raise ValueError(f"Invalid new_channel_init: '{new_channel_init}'")  # :362
+            cur = (cur + 1) % len(bank)
+            rows.append(r)
+        return torch.cat(rows, dim=0)
+
+    def _pos_table(self, C, n_cur, H, W):
+        """[1+n_cur, D] table added to the tokens of every channel (dichavit.py:518-552)."""
+        fe = self.feature_extractor
+        pos = fe.pos_embed
+        n_pos = pos.shape[1] - 1
+        if C * n_cur == n_pos and H == W:  # :529-530 (only reachable with C == 1)
+            return pos[0]
+        P = fe.patch_size
+        g = int(math.sqrt(n_pos))
+        h0, w0 = H // P, W // P
+        # the reference names the first spatial axis `w`; scale factors follow its argument order (:540-545)
+        key = (g, h0, w0, str(pos.device))
+        if key not in self._R_cache:
+            Ry = _bicubic_matrix_1d(g, h0, (h0 + 0.1) / math.sqrt(n_pos)).to(device=pos.device, dtype=torch.float32)
+            Rx = _bicubic_matrix_1d(g, w0, (w0 + 0.1) / math.sqrt(n_pos)).to(device=pos.device, dtype=torch.float32)
+            self._R_cache[key] = (Ry, Rx)
+        Ry, Rx = self._R_cache[key]
+        grid = pos[0, 1:].reshape(g, g, -1)
+        res = _PosResample.apply(grid, Ry, Rx).reshape(h0 * w0, -1)
+        return torch.cat([pos[0, :1], res], dim=0)
+
+    # ---------------------------------------------------------------------------------------
+    # forward / backward drivers (kernel sequences)
+    # ---------------------------------------------------------------------------------------
+    def _run_forward(self, x, ch_idx_dev, C, E, pos_tab, want_ortho, save):
+        fe = self.feature_extractor
+        D, H = self.dim, fe.num_heads
+        P = fe.patch_size
+        B, Ct, Hi, Wi = x.shape
+        n = (Hi // P) * (Wi // P)
+        T, N = C * n, C * n + 1
+        M = B * N
+        dev = x.device
+        bf, f32 = torch.bfloat16, torch.float32
+        self._refresh_operand_copies()
+        pe = fe.patch_embed
+        st = dict(B=B, C=C, n=n, N=N, M=M, save=save)
+        # --- tokeniser: im2col -> MFMA GEMM with (+bias +channel_embed[c] +pos[i]) epilogue ---
+        Xp = torch.empty(B * T, P * P, dtype=bf, device=dev)
+        hip.im2col(x, ch_idx_dev, Xp, B, Ct, C, Hi, Wi, P)
+        xs = torch.empty(B, N, D, dtype=f32, device=dev)
+        Y = torch.empty(B * T, D, dtype=f32, device=dev) if want_ortho else None
+        Ec, pc = E.contiguous(), pos_tab.contiguous()
+        hip.gemm_nt(Xp, self._bf(pe.proj.weight), hip.EPI_PATCH, xs, bias=pe.proj.bias, out2=Y, aux=Ec, aux2=pc, T=T, n=n,
+                    ldo=D, ldo2=D, ldaux=D)
+        hip.fill_cls(xs, fe.cls_token, pc, B, N * D, D)
+        stats = torch.zeros(B, 2, dtype=f32, device=dev)
+        if want_ortho:
+            S = torch.empty(B, C, D, dtype=f32, device=dev)
+            selfsq = torch.empty(B, C, dtype=f32, device=dev)
+            tot = torch.empty(B, D, dtype=f32, device=dev)
+            inv = torch.empty(B, T, dtype=f32, device=dev)
+            hip.ortho_fwd(Y, S, selfsq, tot, inv, stats, B, C, n, D)
+            if save:
+                st.update(Y=Y, S=S, tot=tot, inv=inv)
+        if save:
+            st["Xp"] = Xp
+        # --- encoder blocks ---
+        scale = 64 ** -0.5
+        layers = []
+        xcur = xs.view(M, D)
+        for blk in fe.blocks:
+            L = {}
+            u1 = torch.empty(M, D, dtype=bf, device=dev)
+            mean1, rstd1 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
+            hip.ln_fwd(xcur, blk.norm1.weight, blk.norm1.bias, u1, mean1, rstd1, M, D, LN_EPS)
+            qkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
+            hip.gemm_nt(u1, self._bf(blk.attn.qkv.weight), hip.EPI_BIAS_BF16, qkv, bias=blk.attn.qkv.bias)
+            o = torch.empty(M, D, dtype=bf, device=dev)
+            lse = torch.empty(B, H, N, dtype=f32, device=dev)
+            hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale)
+            xmid = torch.empty(M, D, dtype=f32, device=dev) if save else xcur
+            hip.gemm_nt(o, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=xcur)
+            u2 = torch.empty(M, D, dtype=bf, device=dev)
+            mean2, rstd2 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
+            hip.ln_fwd(xmid, blk.norm2.weight, blk.norm2.bias, u2, mean2, rstd2, M, D, LN_EPS)
+            z = torch.empty(M, 4 * D, dtype=bf, device=dev)
+            hact = torch.empty(M, 4 * D, dtype=bf, device=dev)
+            hip.gemm_nt(u2, self._bf(blk.mlp.fc1.weight), hip.EPI_BIAS_GELU_BF16, z, bias=blk.mlp.fc1.bias, out2=hact)
+            xout = torch.empty(M, D, dtype=f32, device=dev) if save else xmid
+            hip.gemm_nt(hact, self._bf(blk.mlp.fc2.weight), hip.EPI_BIAS_RESID_F32, xout, bias=blk.mlp.fc2.bias, aux=xmid)
+            if save:
+                L.update(x_in=xcur, u1=u1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x_mid=xmid, u2=u2, mean2=mean2,
+                         rstd2=rstd2, z=z, h=hact)
+                layers.append(L)
+            xcur = xout
+        # --- final LayerNorm on the CLS rows only (dichavit.py:651-652) ---
+        feat = torch.empty(B, D, dtype=f32, device=dev)
+        meanf, rstdf = torch.empty(B, dtype=f32, device=dev), torch.empty(B, dtype=f32, device=dev)
+        hip.ln_fwd(xcur, fe.norm.weight, fe.norm.bias, feat, meanf, rstdf, B, D, LN_EPS, x_row_stride=N * D)
+        st.update(feat=feat, stats=stats)
+        if save:
+            st.update(layers=layers, x_final=xcur, meanf=meanf, rstdf=rstdf, want_ortho=want_ortho)
+        return st
+
+    def _gview(self, ga, p):
+        o = self._enc_off[self._w_index[id(p)]]
+        return ga[o:o + p.numel()].view(p.shape)
+
+    def _run_backward(self, st, dfeat, dstats):
+        fe = self.feature_extractor
+        D, H = self.dim, fe.num_heads
+        B, C, n, N, M = st["B"], st["C"], st["n"], st["N"], st["M"]
+        T = C * n
+        dev = dfeat.device
+        bf, f32 = torch.bfloat16, torch.float32
+        ga = self._new_grad_arena()
+        g = lambda p: self._gview(ga, p)  # noqa: E731
+        dp = self._dp
+        # --- final LayerNorm (CLS rows) ---
+        dx = torch.zeros(M, D, dtype=f32, device=dev)
+        hip.ln_bwd(dfeat, st["x_final"], st["meanf"], st["rstdf"], fe.norm.weight, None, dx, None, g(fe.norm.weight), g(fe.norm.bias),
+                   B, D, x_row_stride=N * D, dx_row_stride=N * D)
+        dxb = torch.empty(M, D, dtype=bf, device=dev)
+        hip.cast_bf16(dx, dxb, M * D)
+        if dp is not None:
+            dp.grad_ready(ga, *self._range_of([fe.norm.weight, fe.norm.bias]))
+        scale = 64 ** -0.5
+        dz = torch.empty(M, 4 * D, dtype=bf, device=dev)
+        du = torch.empty(M, D, dtype=bf, device=dev)
+        dO = torch.empty(M, D, dtype=bf, device=dev)
+        dqkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
+        delta = torch.empty(B, H, N, dtype=f32, device=dev)
+        for li in range(len(fe.blocks) - 1, -1, -1):
+            blk, L = fe.blocks[li], st["layers"][li]
+            # MLP
+            hip.gemm_nt(dxb, self._bf(blk.mlp.fc2.weight, True), hip.EPI_GELU_BWD_BF16, dz, aux=L["z"])
+            hip.gemm_tn_acc(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias))
+            hip.gemm_nt(dz, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du)
+            hip.gemm_tn_acc(dz, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias))
+            hip.ln_bwd(du, L["x_mid"], L["mean2"], L["rstd2"], blk.norm2.weight, dx, dx, dxb, g(blk.norm2.weight), g(blk.norm2.bias), M, D)
+            # attention
+            hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO)
+            hip.gemm_tn_acc(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias))
+            hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
+            hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du)
+            hip.gemm_tn_acc(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias))
+            hip.ln_bwd(du, L["x_in"], L["mean1"], L["rstd1"], blk.norm1.weight, dx, dx, dxb, g(blk.norm1.weight), g(blk.norm1.bias), M, D)
+            L.clear()
+            if dp is not None:
+                dp.grad_ready(ga, *self._range_of([blk.norm1.weight, blk.mlp.fc2.bias]))
+        # --- tokeniser ---
+        pe = fe.patch_embed
+        dYl = None
+        if st["want_ortho"] and dstats is not None:
+            dYl = torch.empty(B * T, D, dtype=f32, device=dev)
+            hip.ortho_bwd(st["Y"], st["S"], st["tot"], st["inv"], dstats.contiguous(), dYl, B, C, n, D)
+        dYb = torch.empty(B * T, D, dtype=bf, device=dev)
+        dE = torch.zeros(C, D, dtype=f32, device=dev)
+        dpos = torch.zeros(n + 1, D, dtype=f32, device=dev)
+        hip.patch_bwd(dx, dYl, dYb, dE, dpos, g(fe.cls_token), B, C, n, D)
+        hip.gemm_tn_acc(dYb, st["Xp"], g(pe.proj.weight), g(pe.proj.bias))
+        if dp is not None:
+            dp.grad_ready(ga, *self._range_of([fe.cls_token, pe.proj.bias]))
+            dp.flush()
+        grads = []
+        for p in self._enc_params:
+            grads.append(self._gview(ga, p) if p.requires_grad else None)
+        return dE, dpos, grads
+
+    def _range_of(self, ps):
+        """[start, end) of the arena slots between the first and the last parameter given (inclusive)."""
+        a = self._enc_off[self._w_index[id(ps[0])]]
+        last = ps[-1]
+        b = self._enc_off[self._w_index[id(last)]] + last.numel()
+        return a, b
+
+    # ---------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, chunk_name: str, training_chunks: Optional[str] = None, init_first_layer=None,
+                new_channel_init=None, **kwargs):
+        if not x.is_cuda:
+            raise RuntimeError("diverse_channel_vit_amd runs only on an MI355X: move the model and the batch to the GPU "
+                               "(there is no CPU fallback; the CPU restatement lives in oracle/ and is test infrastructure)")
+        hip.load()
+        fe = self.feature_extractor
+        pe = fe.patch_embed
+        cfg = self.cfg
+        self._ensure_arena(x.device)
+        x = x.contiguous().float()
+        B, Cin, Hi, Wi = x.shape
+        cur_channels = list(pe.mapper[chunk_name])  # dichavit.py:120
+        if Cin != len(cur_channels):
+            raise ValueError(f"input has {Cin} channels but mapper['{chunk_name}'] lists {len(cur_channels)}")
+        ch_t = torch.tensor(cur_channels, device=x.device)
+        channel_embed = pe.channel_embed(ch_t)  # [Cin, D]  :122
+        idx = list(range(Cin))
+        if self.training and pe.enable_sample:  # :127
+            cur_channels, idx = self._sample_channels(chunk_name, cur_channels, channel_embed)
+            channel_embed = channel_embed[idx]  # :136/212
+        if (not self.training) and (training_chunks is not None):  # :219
+            channel_embed = self._eval_channel_embed(chunk_name, training_chunks, new_channel_init)
+        C = len(idx)
+        P = fe.patch_size
+        n = (Hi // P) * (Wi // P)
+        lam_o = _cfg_get(cfg, "ortho_loss_v1_lambda", 0) or 0
+        lam_p = _cfg_get(cfg, "proxy_loss_lambda", 0) or 0
+        want_ortho = bool(self.training and lam_o > 0)
+        pos_tab = self._pos_table(C, n, Hi, Wi)
+        ch_idx_dev = torch.tensor(idx, dtype=torch.int32, device=x.device)
+        feat, stats = _EncoderFn.apply(self, ch_idx_dev, C, want_ortho, x, channel_embed, pos_tab, *self._enc_params)
+        # --- regularisers (tiny tensors; models/loss_fn.py) ---
+        extra = 0
+        if want_ortho:
+            extra = extra + lam_o * self._ortho_from_stats(stats, C, n)
+        if lam_p > 0 and (self.training or True):
+            # the reference evaluates the proxy term in eval mode too and discards it; skip it there
+            if self.training:
+                prox = pe.channel_emb_proxies[cur_channels]  # global ids  (:401)
+                extra = extra + lam_p * _proxy_loss(prox, channel_embed, torch.eye(C, device=x.device), float(pe.channel_scale))
+        out = self.classifer_head(feat)  # :855
+        if self.training:
+            if isinstance(extra, int) and extra == 0:
+                extra = torch.tensor(0.0, device=out.device)  # :857-858
+            return out, extra
+        return out
+
+    def _ortho_from_stats(self, stats, C, n):
+        """loss_fn.py:44-59 on the per-image (pos_sum, neg_sum)."""
+        cfg = self.cfg
+        T = C * n
+        pos_cnt = float(np.float32(np.float32(C * n * (n - 1)) + np.float32(1e-6)))  # fp32 mask.sum() + 1e-6
+        neg_cnt = float(np.float32(np.float32(T * T - C * n * n) + np.float32(1e-6)))
+        pos = stats[:, 0] / pos_cnt
+        neg = stats[:, 1] / neg_cnt
+        if cfg.use_square:
+            neg = neg ** 2
+        if cfg.reverse_pos_pairs:
+            if cfg.use_square:
+                pos = pos ** 2
+            loss = cfg.gamma_s * pos + cfg.gamma_d * neg
+        else:
+            loss = cfg.gamma_s * (1.0 - pos) + cfg.gamma_d * neg
+        return loss.mean()
+
+
+def _proxy_loss(proxies, emb, target, scale):
+    """proxy_loss (models/loss_fn.py:7-21): -cdist^2 logits, mean CE with class-index or probability targets."""
+    p = scale * F.normalize(proxies, p=2, dim=-1)
+    e = scale * F.normalize(emb, p=2, dim=-1)
+    d2 = ((e[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+    return F.cross_entropy(-d2, target)
+
+
+proxy_loss = _proxy_loss  # the CHAMMI step calls it with model.proxies (trainer.py:913)
+
+
+def dichavit(cfg, **kwargs) -> DiChaViT:  # models/dichavit.py:864-865
+    return DiChaViT(config=cfg, **kwargs)

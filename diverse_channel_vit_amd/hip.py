@@ -1,0 +1,200 @@
+"""ctypes binding of libdcv_hip.so (include/dcv.h).  Thin: tensors in, raw device pointers +
+sizes + the current torch stream out.  There is NO fallback: if the library is missing or a call
+returns an error code, this raises.  PyTorch is used only for device memory and streams."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdcv_hip.so")
+
+EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RESID_F32, EPI_PLAIN_BF16, EPI_GELU_BWD_BF16, EPI_PATCH = range(6)
+
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
+_SIGS = {
+    "dcv_version": ([], C.c_int),
+    "dcv_error_string": ([_i], C.c_char_p),
+    "dcv_gemm_nt": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp], _i),
+    "dcv_gemm_tn_acc": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp], _i),
+    "dcv_ln_fwd": ([_vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp], _i),
+    "dcv_ln_bwd": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "dcv_attn_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd_delta": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "dcv_attn_bwd_dq": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd_dkdv": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_im2col_bf16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "dcv_patch_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "dcv_fill_cls": ([_vp, _vp, _vp, _i, _l, _i, _vp], _i),
+    "dcv_ortho_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "dcv_ortho_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "dcv_adamw": ([_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
+    "dcv_cast_bf16": ([_vp, _vp, _l, _vp], _i),
+    "dcv_cast_transpose_bf16": ([_vp, _vp, _vp, _i, _i, _vp], _i),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the in-tree library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is the only compute path of diverse_channel_vit_amd. "
+                "Build it with `python -m diverse_channel_vit_amd._build` (needs hipcc, gfx950).")
+        lib = C.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = lib
+    return _lib
+
+
+# optional per-entry timing with events on the launch stream (bench.py): {name: [(start, end), ...]}
+_prof = None
+
+
+def set_profiler(names=None):
+    """names: iterable of entry names to time (None disables).  Returns the previous records."""
+    global _prof
+    old = _prof
+    _prof = None if names is None else {n: [] for n in names}
+    return old
+
+
+class _timed:
+    def __init__(self, name):
+        self.rec = None if _prof is None else _prof.get(name)
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+
+    def __exit__(self, *a):
+        if self.rec is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.rec.append((self.s, e))
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {load().dcv_error_string(rc).decode()} ({rc})")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T=0, n=0, ldo=None, ldo2=None, ldaux=None):
+    """C = A[M,K] @ W[N,K]^T with the given epilogue (see include/dcv.h)."""
+    _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W")
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K
+    ldo = out.shape[-1] if ldo is None else ldo
+    ldo2 = (out2.shape[-1] if out2 is not None else 0) if ldo2 is None else ldo2
+    ldaux = (aux.shape[-1] if aux is not None else 0) if ldaux is None else ldaux
+    with _timed("gemm_nt"):
+        rc = load().dcv_gemm_nt(_p(A), K, _p(W), K, M, N, K, epilogue, _p(bias), _p(out), ldo, _p(out2), ldo2, _p(aux), ldaux,
+                                _p(aux2), T, n, _stream())
+    _check(rc, "dcv_gemm_nt")
+
+
+def gemm_tn_acc(Y, X, dW, dbias=None):
+    """dW[P,Q] += Y[M,P]^T @ X[M,Q]; dbias[P] += colsum(Y)."""
+    _req(Y, torch.bfloat16, "Y"); _req(X, torch.bfloat16, "X"); _req(dW, torch.float32, "dW")
+    M, P = Y.shape
+    Q = X.shape[1]
+    assert X.shape[0] == M and dW.numel() == P * Q
+    with _timed("gemm_tn"):
+        rc = load().dcv_gemm_tn_acc(_p(Y), P, _p(X), Q, M, P, Q, _p(dW), Q, _p(dbias), _stream())
+    _check(rc, "dcv_gemm_tn_acc")
+
+
+def ln_fwd(x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride=None):
+    with _timed("ln_fwd"):
+        rc = load().dcv_ln_fwd(_p(x), D if x_row_stride is None else x_row_stride, _p(gamma), _p(beta), _p(out),
+                               1 if out.dtype == torch.float32 else 0, _p(mean), _p(rstd), M, D, eps, _stream())
+    _check(rc, "dcv_ln_fwd")
+
+
+def ln_bwd(du, x, mean, rstd, gamma, dx_in, dx_out, dx_bf16, dgamma, dbeta, M, D, x_row_stride=None, dx_row_stride=None):
+    with _timed("ln_bwd"):
+        rc = load().dcv_ln_bwd(_p(du), 1 if du.dtype == torch.float32 else 0, _p(x), D if x_row_stride is None else x_row_stride,
+                               _p(mean), _p(rstd), _p(gamma), _p(dx_in), _p(dx_out), D if dx_row_stride is None else dx_row_stride,
+                               _p(dx_bf16), _p(dgamma), _p(dbeta), M, D, _stream())
+    _check(rc, "dcv_ln_bwd")
+
+
+def attn_fwd(qkv, o, lse, B, N, H, hd, scale):
+    _req(qkv, torch.bfloat16, "qkv")
+    with _timed("attn_fwd"):
+        rc = load().dcv_attn_fwd(_p(qkv), _p(o), _p(lse), B, N, H, hd, scale, _stream())
+    _check(rc, "dcv_attn_fwd")
+
+
+def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale):
+    lib = load()
+    _check(lib.dcv_attn_bwd_delta(_p(o), _p(dO), _p(delta_ws), B, N, H, hd, _stream()), "dcv_attn_bwd_delta")
+    with _timed("attn_bwd_dq"):
+        rc = lib.dcv_attn_bwd_dq(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, H, hd, scale, _stream())
+    _check(rc, "dcv_attn_bwd_dq")
+    with _timed("attn_bwd_dkdv"):
+        rc = lib.dcv_attn_bwd_dkdv(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, H, hd, scale, _stream())
+    _check(rc, "dcv_attn_bwd_dkdv")
+
+
+def im2col(x, ch_idx, out, B, Ct, C, H, W, P):
+    _req(x, torch.float32, "x"); _req(ch_idx, torch.int32, "ch_idx")
+    _check(load().dcv_im2col_bf16(_p(x), _p(ch_idx), _p(out), B, Ct, C, H, W, P, _stream()), "dcv_im2col_bf16")
+
+
+def patch_bwd(dx0, dYloss, dY_bf16, dE, dpos, dcls, B, C, n, D):
+    _check(load().dcv_patch_bwd(_p(dx0), _p(dYloss), _p(dY_bf16), _p(dE), _p(dpos), _p(dcls), B, C, n, D, _stream()), "dcv_patch_bwd")
+
+
+def fill_cls(x, cls, pos0, B, batch_stride, D):
+    _check(load().dcv_fill_cls(_p(x), _p(cls), _p(pos0), B, batch_stride, D, _stream()), "dcv_fill_cls")
+
+
+def ortho_fwd(Y, S, selfsq, tot, inv_norm, stats, B, Cc, n, D):
+    _check(load().dcv_ortho_fwd(_p(Y), _p(S), _p(selfsq), _p(tot), _p(inv_norm), _p(stats), B, Cc, n, D, _stream()), "dcv_ortho_fwd")
+
+
+def ortho_bwd(Y, S, tot, inv_norm, coef, dY, B, Cc, n, D):
+    _check(load().dcv_ortho_bwd(_p(Y), _p(S), _p(tot), _p(inv_norm), _p(coef), _p(dY), B, Cc, n, D, _stream()), "dcv_ortho_bwd")
+
+
+def adamw(p, g, m, v, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+    _check(load().dcv_adamw(_p(p), _p(g), _p(m), _p(v), n, lr, b1, b2, eps, wd, step, grad_scale, _stream()), "dcv_adamw")
+
+
+def cast_bf16(src, dst, n):
+    _check(load().dcv_cast_bf16(_p(src), _p(dst), n, _stream()), "dcv_cast_bf16")
+
+
+def cast_transpose_bf16(src_base, dst_base, desc_dev, n_desc, max_tiles):
+    _check(load().dcv_cast_transpose_bf16(_p(src_base), _p(dst_base), _p(desc_dev), n_desc, max_tiles, _stream()), "dcv_cast_transpose_bf16")

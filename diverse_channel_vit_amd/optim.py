@@ -1,0 +1,82 @@
+"""Fused AdamW over the model's flat parameter/gradient arenas.
+
+Restates what the reference builds with ``make_my_optimizer('adamw', ...)`` -> timm AdamW
+(optimizers.py:20-21, trainer.py:1224-1230): ONE parameter group, decoupled weight decay on every
+parameter that has a gradient (LayerNorm/bias/pos/cls included), bias-corrected Adam.  lr and
+weight_decay are read from ``param_groups[0]`` every step, so the reference's per-epoch LR scheduler
+and per-step weight-decay schedule (trainer.py:1009-1019) drive it unchanged.
+
+When every encoder parameter's ``.grad`` aliases the model's gradient arena (the normal
+zero_grad(set_to_none=True) -> backward flow) the whole encoder (≈99.7 % of the parameters) is
+updated by ONE kernel launch over one contiguous range; anything else takes one launch per tensor.
+Parameters whose grad is None are skipped, exactly like torch/timm AdamW."""
+from __future__ import annotations
+
+import torch
+
+from . import hip
+
+
+class HipAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError("HipAdamW mirrors the reference's single parameter group")
+        self.model = model
+        self._step = 0
+        self._m = self._v = None
+
+    def _ensure_state(self):
+        model = self.model
+        arena = model._arena
+        if self._m is None or self._m.shape != arena.shape or self._m.device != arena.device:
+            self._m = torch.zeros_like(arena)
+            self._v = torch.zeros_like(arena)
+            for p, o in zip(model._all_params, model._all_off):
+                st = self.state[p]
+                st["exp_avg"] = self._m[o:o + p.numel()].view(p.shape)
+                st["exp_avg_sq"] = self._v[o:o + p.numel()].view(p.shape)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        model = self.model
+        if model is None or model._arena is None:
+            raise RuntimeError("HipAdamW needs the arena-backed DiChaViT it optimises (pass model=...) after its first forward")
+        if model._dp is not None:
+            model._dp.finalize()
+        self._ensure_state()
+        grp = self.param_groups[0]
+        lr, (b1, b2), eps, wd = float(grp["lr"]), grp["betas"], float(grp["eps"]), float(grp["weight_decay"])
+        self._step += 1
+        step = self._step
+        mine = {id(p) for p in grp["params"]}
+        ga = model._grad_arena
+        enc = model._enc_params
+        fused = ga is not None and all(
+            id(p) in mine and p.grad is not None and p.grad.data_ptr() == ga.data_ptr() + o * 4
+            for p, o in zip(enc, model._enc_off))
+        done = set()
+        if fused:
+            n = model._enc_size
+            hip.adamw(model._arena, ga, self._m, self._v, n, lr, b1, b2, eps, wd, step, 1.0)
+            done = {id(p) for p in enc}
+        off = {id(p): o for p, o in zip(model._all_params, model._all_off)}
+        for p in grp["params"]:
+            if id(p) in done or p.grad is None:
+                continue
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            o = off.get(id(p))
+            if o is None:
+                raise RuntimeError("parameter is not part of the model's arena")
+            n = p.numel()
+            if (o * 4) % 16 or g.data_ptr() % 16:
+                raise RuntimeError("unaligned parameter slot")
+            hip.adamw(model._arena[o:o + n], g, self._m[o:o + n], self._v[o:o + n], n, lr, b1, b2, eps, wd, step, 1.0)
+        for p in grp["params"]:
+            self.state[p]["step"] = step
+        return loss

@@ -1,0 +1,99 @@
+/* libdcv_hip.so — C ABI of the MI355X-native DiChaViT training hot path.
+ *
+ * The reference (chaudatascience/diverse_channel_vit) has NO FFI: its hot path is stock ATen ops
+ * called from Python.  The drop-in boundary is therefore the Python plugin contract
+ * (models/__init__.py:9 `dichavit`, models/dichavit.py:844-865), mirrored by
+ * diverse_channel_vit_amd/dichavit.py.  This header is the native layer beneath it: each entry
+ * replaces the ATen op sequence cited next to it.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions: every entry returns 0 or a negative DCV_ERR_* code; never throws, never allocates,
+ * never synchronises; all buffers are device pointers owned by the caller; `stream` is a hipStream_t
+ * (pass torch.cuda.current_stream().cuda_stream); entries are re-entrant (no global mutable state).
+ * bf16 buffers are raw 16-bit brain-float; "f32" is IEEE binary32.  Only gfx950 code is built.
+ */
+#ifndef DCV_H
+#define DCV_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCV_OK 0
+#define DCV_ERR_SHAPE (-1)
+#define DCV_ERR_ALIGN (-2)
+#define DCV_ERR_UNSUPPORTED (-3)
+#define DCV_ERR_LAUNCH (-4)
+#define DCV_ERR_NULL (-5)
+
+/* dcv_gemm_nt epilogues */
+#define DCV_EPI_BIAS_BF16 0      /* out bf16 = acc + bias                         (attn.qkv, vit.py:123)            */
+#define DCV_EPI_BIAS_GELU_BF16 1 /* out bf16 = z = acc + bias ; out2 bf16 = GELU_erf(z) (mlp.fc1 + act, vit.py:77-78) */
+#define DCV_EPI_BIAS_RESID_F32 2 /* out f32 = (aux f32 ? aux : out) + acc + bias (attn.proj / mlp.fc2 + residual, vit.py:142,397-398) */
+#define DCV_EPI_PLAIN_BF16 3     /* out bf16 = acc                                 (input gradients)                */
+#define DCV_EPI_GELU_BWD_BF16 4  /* out bf16 = acc * GELU'(aux bf16)               (grad through act, vit.py:78)    */
+#define DCV_EPI_PATCH 5          /* tokens: out f32[b,1+t,:] = acc + bias + aux[c(t),:] + aux2[1+i(t),:] ;
+                                    out2 f32[b*T+t,:] = acc + bias (optional)       (dichavit.py:377,409-415,565)   */
+
+int dcv_version(void);
+const char* dcv_error_string(int code);
+
+/* C[M,N] = A[M,K] . W[N,K]^T (bf16 in, f32 accumulate) + epilogue.  K % 64 == 0, lda/ldw % 8 == 0.
+ * Replaces F.linear forward / input-gradient and the Conv3d patch projection (on im2col rows). */
+int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue, const float* bias,
+                void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux, const float* aux2, int T, int n,
+                void* stream);
+
+/* dW[P,Q] (f32) += sum_m Y[m,P] * X[m,Q] ; dbias[P] (f32, nullable) += sum_m Y[m,P].  bf16 inputs.
+ * Replaces the weight/bias gradients of nn.Linear / Conv3d (autograd of vit.py:72-74,123,142; dichavit.py:377). */
+int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias,
+                    void* stream);
+
+/* LayerNorm (eps inside the sqrt, biased variance) — vit.py:361,374 / dichavit.py:651.
+ * out is bf16 [M,D] (or f32 when out_is_f32); mean/rstd [M] may be NULL. x rows are x_row_stride floats apart. */
+int dcv_ln_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, void* out, int out_is_f32, float* mean,
+               float* rstd, int M, int D, float eps, void* stream);
+/* dx_out = (dx_in ? dx_in : 0) + LN'(du) ; dx_bf16 (nullable) = bf16(dx_out) ; dgamma/dbeta += ... */
+int dcv_ln_bwd(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
+               const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
+               float* dbeta, int M, int D, void* stream);
+
+/* softmax(q k^T * scale) v for packed qkv [B,N,3,H,64] bf16 -> o [B,N,H*64] bf16, lse [B,H,N] f32.
+ * Replaces Attention.forward's q@k^T / softmax / @v (vit.py:123-141); the [B,H,N,N] matrix is never stored. */
+int dcv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale, void* stream);
+/* dqkv [B,N,3,H,64] bf16 from (qkv, o, dO, lse); delta_ws: f32 workspace [B,H,N]. */
+int dcv_attn_bwd(const void* qkv, const void* o, const void* dO, const float* lse, float* delta_ws, void* dqkv, int B, int N,
+                 int H, int head_dim, float scale, void* stream);
+/* the three launches dcv_attn_bwd makes, individually (profiling / stream placement):
+ * delta[b,h,q] = sum_d dO*O ; dQ slot of dqkv ; dK and dV slots of dqkv. */
+int dcv_attn_bwd_delta(const void* o, const void* dO, float* delta_ws, int B, int N, int H, int head_dim, void* stream);
+int dcv_attn_bwd_dq(const void* qkv, const void* dO, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
+                    int head_dim, float scale, void* stream);
+int dcv_attn_bwd_dkdv(const void* qkv, const void* dO, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
+                      int head_dim, float scale, void* stream);
+
+/* x f32 [B,Ct,H,W], ch_idx int32[C] (device) -> bf16 [B*C*(H/P)*(W/P), P*P] patch rows (dichavit.py:134/210,377). */
+int dcv_im2col_bf16(const float* x, const int* ch_idx, void* out, int B, int Ct, int C, int H, int W, int P, void* stream);
+/* one pass over d(tokens) f32 [B,1+C*n,D]: dY_bf16 [B*C*n,D] = dx0[:,1:] (+ dYloss) ; dE [C,D], dpos [1+n,D], dcls [D] += */
+int dcv_patch_bwd(const float* dx0, const float* dYloss, void* dY_bf16, float* dE, float* dpos, float* dcls, int B, int C, int n,
+                  int D, void* stream);
+int dcv_fill_cls(float* x, const float* cls, const float* pos0, int B, long batch_stride, int D, void* stream);
+
+/* ortho_proj_loss_fn_v2 statistics (loss_fn.py:24-48): stats[b] = (pos_sum, neg_sum) of image b.
+ * S [B,C,D], selfsq [B,C], tot [B,D], inv_norm [B,C*n] are outputs kept for the backward. */
+int dcv_ortho_fwd(const float* Y, float* S, float* selfsq, float* tot, float* inv_norm, float* stats, int B, int C, int n, int D,
+                  void* stream);
+/* dY [B,C*n,D] f32 = d loss / dY given coef[b] = (dL/dpos_sum_b, dL/dneg_sum_b). */
+int dcv_ortho_bwd(const float* Y, const float* S, const float* tot, const float* inv_norm, const float* coef, float* dY, int B,
+                  int C, int n, int D, void* stream);
+
+/* fused AdamW over a flat fp32 range; g is multiplied by grad_scale first (1/world for data parallel). */
+int dcv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+              float weight_decay, int step, float grad_scale, void* stream);
+/* bf16 operand copies of the parameter arena */
+int dcv_cast_bf16(const float* src, void* dst, long n, void* stream);
+/* desc_dev: device int64 [n_desc][4] = {src offset, dst offset, R, C}; dst[C][R] = bf16(src[R][C]) */
+int dcv_cast_transpose_bf16(const float* src_base, void* dst_base, const long long* desc_dev, int n_desc, int max_tiles, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

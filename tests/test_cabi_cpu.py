@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/dcv.h declares (no compute call is made without a GPU), and the product path refuses to run
+on the CPU instead of falling back."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "dcv.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from diverse_channel_vit_amd import _build, hip
+    if not os.path.exists(hip.LIB_PATH):
+        _build.build(verbose=False)
+    lib = hip.load()
+    names = _declared()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/dcv.h but not exported"
+    assert sorted(hip.EXPORTS) == names, "ctypes signature table and header disagree"
+    assert lib.dcv_version() >= 100
+    assert lib.dcv_error_string(-3).decode().startswith("unsupported")
+
+
+def test_no_cpu_fallback_and_state_dict_layout():
+    import diverse_channel_vit_amd as dcv
+    from conftest import load_golden
+    meta, _ = load_golden("so2sat_s")
+
+    class Cfg(dict):
+        __getattr__ = dict.get
+
+    cfg = Cfg(meta["cfg"], in_channel_names=[f"c{i}" for i in range(18)], img_size=[32], num_classes=17)
+    model = dcv.dichavit(cfg, mapper={"train": list(range(18))})
+    assert sorted(model.state_dict().keys()) == sorted(meta["state_keys"])  # the reference's 156 keys
+    assert sum(p.numel() for p in model.parameters()) == 21353105  # SURVEY §8a a1 (So2Sat S)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(2, 18, 32, 32), "train", None)
+    for bad in (dict(block_type="block_v2"), dict(block_type="nope"), dict(pretrained_model_name="huge")):
+        with pytest.raises(ValueError):
+            dcv.dichavit(Cfg(cfg, **bad), mapper={"train": list(range(18))})
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "diverse_channel_vit_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            txt = open(os.path.join(pkg, f)).read()
+            assert "import oracle" not in txt and "from oracle" not in txt, f

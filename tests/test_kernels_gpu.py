@@ -1,0 +1,261 @@
+"""Per-kernel parity: every entry of include/dcv.h against plain fp32 torch math (or the oracle's
+formula) on the same seeded inputs.  Tolerances are the bf16 rounding of inputs/outputs; all
+accumulation in the kernels is fp32.  Needs an MI355X: run with -m gpu."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(gpu_device):
+    from diverse_channel_vit_amd import hip as h
+    h.load()
+    return h
+
+
+def _bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).cuda()
+
+
+def _f(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def _close(a, b, rtol, atol, what=""):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max().item():.4g} (ref max {b.abs().max().item():.4g})"
+
+
+GEMM_SHAPES = [(300, 384, 384), (128, 128, 64), (777, 1152, 384), (1000, 384, 1536), (257, 192, 192), (130, 576, 192)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_epilogues(hip, M, N, K):
+    A, W = _bf(M, K, seed=1), _bf(N, K, scale=0.05, seed=2)
+    bias = _f(N, scale=0.1, seed=3)
+    ref = A.float() @ W.float().t()
+    # bias -> bf16
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    hip.gemm_nt(A, W, hip.EPI_BIAS_BF16, out, bias=bias)
+    _close(out, ref + bias, 1e-2, 2e-2, "bias_bf16")
+    # plain
+    hip.gemm_nt(A, W, hip.EPI_PLAIN_BF16, out)
+    _close(out, ref, 1e-2, 2e-2, "plain_bf16")
+    # bias + gelu (z and h)
+    h = torch.empty_like(out)
+    hip.gemm_nt(A, W, hip.EPI_BIAS_GELU_BF16, out, bias=bias, out2=h)
+    _close(out, ref + bias, 1e-2, 2e-2, "gelu z")
+    _close(h, torch.nn.functional.gelu(out.float()), 1e-2, 1e-2, "gelu h")
+    # residual f32 in place
+    x = _f(M, N, seed=4)
+    x0 = x.clone()
+    hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, x, bias=bias)
+    _close(x, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32")
+    y = torch.empty_like(x)
+    hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, y, bias=bias, aux=x0)  # out-of-place residual
+    _close(y, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32 out-of-place")
+    assert torch.equal(y, x)
+    # gelu backward epilogue
+    z = _bf(M, N, seed=5)
+    hip.gemm_nt(A, W, hip.EPI_GELU_BWD_BF16, out, aux=z)
+    zf = z.float().requires_grad_(True)
+    torch.nn.functional.gelu(zf).sum().backward()
+    _close(out, ref * zf.grad, 1e-2, 2e-2, "gelu_bwd")
+
+
+def test_gemm_nt_patch_epilogue(hip):
+    B, C, n, D, PP = 3, 5, 16, 384, 64
+    T = C * n
+    A, W = _bf(B * T, PP, seed=1), _bf(D, PP, scale=0.1, seed=2)
+    bias, E, pos = _f(D, seed=3), _f(C, D, seed=4), _f(n + 1, D, seed=5)
+    x = torch.full((B, T + 1, D), 7.0, device="cuda")
+    Y = torch.empty(B * T, D, device="cuda")
+    hip.gemm_nt(A, W, hip.EPI_PATCH, x, bias=bias, out2=Y, aux=E, aux2=pos, T=T, n=n, ldo=D)
+    ref = (A.float() @ W.float().t() + bias).reshape(B, T, D)
+    _close(Y.reshape(B, T, D), ref, 1e-5, 1e-4, "Y")
+    tok = ref + E.repeat_interleave(n, 0)[None] + pos[1:].repeat(C, 1)[None]
+    _close(x[:, 1:], tok, 1e-5, 1e-4, "tokens")
+    assert (x[:, 0] == 7.0).all()
+
+
+@pytest.mark.parametrize("M,P,Q", [(1000, 384, 384), (4100, 1152, 384), (333, 384, 1536), (64, 128, 128), (5000, 192, 64), (700, 384, 256)])
+def test_gemm_tn(hip, M, P, Q):
+    Y, X = _bf(M, P, seed=1), _bf(M, Q, seed=2)
+    dW = _f(P, Q, seed=3)
+    db = _f(P, seed=4)
+    dW0, db0 = dW.clone(), db.clone()
+    hip.gemm_tn_acc(Y, X, dW, db)
+    ref = Y.float().t() @ X.float()
+    _close(dW, dW0 + ref, 1e-4, 3e-4 * math.sqrt(M), "dW")
+    _close(db, db0 + Y.float().sum(0), 1e-4, 1e-4 * math.sqrt(M), "dbias")
+    dW2 = torch.zeros(P, Q, device="cuda")
+    hip.gemm_tn_acc(Y, X, dW2, None)
+    _close(dW2, ref, 1e-4, 3e-4 * math.sqrt(M), "dW no bias")
+
+
+@pytest.mark.parametrize("M,D", [(1000, 384), (37, 192), (513, 768)])
+def test_layernorm(hip, M, D):
+    x = _f(M, D, scale=2.0, seed=1) + 0.5
+    g, b = 1 + 0.1 * _f(D, seed=2), 0.1 * _f(D, seed=3)
+    u = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    hip.ln_fwd(x, g, b, u, mean, rstd, M, D, 1e-6)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    _close(u, ref, 1e-2, 1e-2, "ln fwd")
+    _close(mean, x.mean(-1), 1e-5, 1e-5, "mean")
+    uf = torch.empty(M, D, device="cuda")
+    hip.ln_fwd(x, g, b, uf, None, None, M, D, 1e-6)
+    _close(uf, ref, 1e-5, 1e-5, "ln fwd f32")
+    du = _bf(M, D, seed=4)
+    dx_in = _f(M, D, seed=5)
+    ref.backward(du.float())
+    dx = torch.empty(M, D, device="cuda")
+    dxb = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+    hip.ln_bwd(du, x, mean, rstd, g, dx_in, dx, dxb, dg, db, M, D)
+    _close(dx, dx_in + xr.grad, 1e-4, 1e-4, "ln dx")
+    _close(dxb, dx_in + xr.grad, 1e-2, 1e-2, "ln dx bf16")
+    _close(dg, gr.grad, 1e-4, 1e-3, "dgamma")
+    _close(db, br.grad, 1e-4, 1e-3, "dbeta")
+    # in-place accumulate form (dx_in aliases dx_out) and f32 du
+    dx2 = dx_in.clone()
+    dg.zero_(); db.zero_()
+    hip.ln_bwd(du.float(), x, mean, rstd, g, dx2, dx2, None, dg, db, M, D)
+    _close(dx2, dx_in + xr.grad, 1e-4, 1e-4, "ln dx inplace")
+
+
+def _attn_ref(qkv, B, N, H, scale):
+    q, k, v = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * scale
+    p = s.softmax(-1)
+    o = (p @ v).transpose(1, 2).reshape(B, N, H * 64)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 64, 1), (2, 289, 6), (1, 1569, 6), (3, 130, 2), (8, 50, 1)])
+def test_attention_fwd_bwd(hip, B, N, H):
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = _bf(B, N, 3 * D, scale=1.5, seed=N)
+    # spike one key against one query so a late tile raises the running max (online-softmax rescale path)
+    qkv[0, N // 2, :64] *= 4
+    qkv[0, N - 1, D:D + 64] = qkv[0, N // 2, :64]
+    o = torch.empty(B, N, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    hip.attn_fwd(qkv, o, lse, B, N, H, 64, scale)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, B, N, H, scale)
+    _close(o, o_ref, 2e-2, 2e-2, "attn O")
+    _close(lse, lse_ref, 1e-4, 2e-3, "attn LSE")
+    dO = _bf(B, N, D, seed=7)
+    o_ref.backward(dO.float())
+    dqkv = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    delta = torch.empty(B, H, N, device="cuda")
+    hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, scale)
+    assert torch.isfinite(dqkv.float()).all()
+    g = qr.grad.reshape(B, N, 3, D)
+    d = dqkv.float().reshape(B, N, 3, D)
+    for i, nm in enumerate(["dQ", "dK", "dV"]):
+        ref = g[:, :, i]
+        tol = 3e-2 * ref.abs().max().item()
+        _close(d[:, :, i], ref, 3e-2, tol, nm)
+
+
+def test_im2col(hip):
+    from oracle import dichavit_oracle as orc
+    B, Ct, H, P = 3, 6, 32, 8
+    x = _f(B, Ct, H, H, seed=1)
+    idx = torch.tensor([4, 0, 5], dtype=torch.int32, device="cuda")
+    n = (H // P) ** 2
+    out = torch.empty(B * 3 * n, P * P, dtype=torch.bfloat16, device="cuda")
+    hip.im2col(x, idx, out, B, Ct, 3, H, H, P)
+    ref = orc.unfold_patches(x[:, idx.long()].cpu(), P).reshape(B * 3 * n, P * P)
+    assert torch.equal(out.cpu(), ref.to(torch.bfloat16))
+    B, Ct, H, P = 2, 8, 224, 16
+    x = _f(B, Ct, H, H, seed=2)
+    idx = torch.arange(8, dtype=torch.int32, device="cuda")
+    out = torch.empty(B * 8 * 196, 256, dtype=torch.bfloat16, device="cuda")
+    hip.im2col(x, idx, out, B, Ct, 8, H, H, P)
+    assert torch.equal(out.cpu(), orc.unfold_patches(x.cpu(), P).reshape(-1, 256).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,C,n,D", [(3, 5, 16, 384), (2, 1, 9, 192), (4, 8, 49, 768)])
+def test_patch_bwd(hip, B, C, n, D):
+    T = C * n
+    dx0, dYl = _f(B, T + 1, D, seed=1), _f(B, T, D, seed=2)
+    dYb = torch.empty(B * T, D, dtype=torch.bfloat16, device="cuda")
+    dE, dpos, dcls = torch.zeros(C, D, device="cuda"), torch.zeros(n + 1, D, device="cuda"), torch.zeros(D, device="cuda")
+    hip.patch_bwd(dx0, dYl, dYb, dE, dpos, dcls, B, C, n, D)
+    tok = dx0[:, 1:]
+    _close(dYb.reshape(B, T, D), tok + dYl, 1e-2, 1e-2, "dY")
+    _close(dE, tok.reshape(B, C, n, D).sum((0, 2)), 1e-5, 1e-4, "dE")
+    _close(dpos[1:], tok.reshape(B, C, n, D).sum((0, 1)), 1e-5, 1e-4, "dpos")
+    _close(dpos[0], dx0[:, 0].sum(0), 1e-5, 1e-4, "dpos0")
+    _close(dcls, dx0[:, 0].sum(0), 1e-5, 1e-4, "dcls")
+    hip.patch_bwd(dx0, None, dYb, dE, dpos, dcls, B, C, n, D)
+    _close(dYb.reshape(B, T, D), tok, 1e-2, 1e-2, "dY no loss")
+
+
+@pytest.mark.parametrize("B,C,n,D", [(3, 5, 16, 384), (2, 1, 9, 192), (2, 8, 196, 384), (2, 18, 16, 384)])
+def test_ortho_loss(hip, B, C, n, D):
+    from oracle import dichavit_oracle as orc
+    T = C * n
+    Y = _f(B, T, D, seed=3) + 0.3
+    S, selfsq = torch.empty(B, C, D, device="cuda"), torch.empty(B, C, device="cuda")
+    tot, inv, stats = torch.empty(B, D, device="cuda"), torch.empty(B, T, device="cuda"), torch.empty(B, 2, device="cuda")
+    hip.ortho_fwd(Y, S, selfsq, tot, inv, stats, B, C, n, D)
+    Yr = Y.double().cpu().requires_grad_(True)
+    f = torch.nn.functional.normalize(Yr, dim=-1).reshape(B, C, n, D)
+    s = f.sum(2)
+    pos_sum = ((s * s).sum(-1) - (f * f).sum(-1).sum(-1)).sum(-1)
+    neg_sum = (s.sum(1) ** 2).sum(-1) - (s * s).sum(-1).sum(-1)
+    _close(stats[:, 0].cpu(), pos_sum.detach(), 1e-4, 1e-3 * max(1.0, pos_sum.abs().max().item()), "pos_sum")
+    if C > 1:
+        _close(stats[:, 1].cpu(), neg_sum.detach(), 1e-4, 1e-3 * max(1.0, neg_sum.abs().max().item()), "neg_sum")
+    else:
+        assert (stats[:, 1] == 0).all()
+    coef = _f(B, 2, seed=9)
+    loss = (coef[:, 0].double().cpu() * pos_sum).sum() + ((coef[:, 1].double().cpu() * neg_sum).sum() if C > 1 else 0)
+    loss.backward()
+    dY = torch.empty_like(Y)
+    hip.ortho_bwd(Y, S, tot, inv, coef, dY, B, C, n, D)
+    _close(dY.cpu(), Yr.grad, 1e-3, 1e-4 * Yr.grad.abs().max().item() + 1e-6, "dY")
+    # value parity with the oracle's full loss formula
+    val = orc.ortho_loss_linear(Y.double().cpu(), C, n, 1.0, 4.0, True, False).item()
+    pos = stats[:, 0].double().cpu() / orc._count_eps(C * n * (n - 1))
+    neg = stats[:, 1].double().cpu() / orc._count_eps(T * T - C * n * n) if C > 1 else torch.zeros(B, dtype=torch.float64)
+    assert abs((pos + 4.0 * neg).mean().item() - val) < 1e-5 * max(1.0, abs(val))
+
+
+def test_adamw_and_casts(hip):
+    from oracle import dichavit_oracle as orc
+    n = 100003
+    p, g = _f(n, seed=1), _f(n, scale=0.01, seed=2)
+    m, v = torch.zeros(n + 1, device="cuda")[:n], torch.zeros(n + 1, device="cuda")[:n]
+    pc, gc, mc, vc = p.cpu().clone(), g.cpu().clone(), torch.zeros(n), torch.zeros(n)
+    for step in (1, 2, 3):
+        hip.adamw(p, g, m, v, n, 4.9e-5, 0.9, 0.999, 1e-8, 0.04, step, 0.5)
+        orc.adamw_step(pc, gc * 0.5, mc, vc, step, 4.9e-5, 0.9, 0.999, 1e-8, 0.04)
+    _close(p.cpu(), pc, 1e-6, 1e-7, "adamw p")
+    _close(v.cpu(), vc, 1e-4, 1e-12, "adamw v")
+    dst = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    hip.cast_bf16(p, dst, n)
+    assert torch.equal(dst, p.to(torch.bfloat16))
+    # batched transpose
+    src = _f(1152 * 384 + 100 * 70, seed=5)
+    out = torch.zeros(src.numel(), dtype=torch.bfloat16, device="cuda")
+    desc = torch.tensor([[0, 0, 1152, 384], [1152 * 384, 1152 * 384, 100, 70]], dtype=torch.int64, device="cuda")
+    hip.cast_transpose_bf16(src, out, desc, 2, 18 * 6)
+    assert torch.equal(out[:1152 * 384].reshape(384, 1152), src[:1152 * 384].reshape(1152, 384).t().to(torch.bfloat16))
+    assert torch.equal(out[1152 * 384:].reshape(70, 100), src[1152 * 384:].reshape(100, 70).t().to(torch.bfloat16))
