@@ -43,10 +43,15 @@ def model_cfg(arch="small", channels=8, img=224, patch=16, classes=161):
                in_channel_names=[f"c{i}" for i in range(channels)], img_size=[img], num_classes=classes)
 
 
-def cpu_baseline(cfg, channels, img, classes, sample_bs=2, steps=3):
+def cpu_baseline(cfg, channels, img, classes, sample_bs=2, steps=2):
     """The oracle (CPU restatement of the reference's path, fp32) timed on this host: baseline only."""
     from oracle import dichavit_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the box's CPU share, not the host's core count (an oversubscribed pool is many times slower)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))
     shapes = orc.state_shapes(cfg, channels, img, classes)
     sd = orc.make_state(shapes, 0)
     names = [k for k in sd if k != "proxies"]

@@ -10,6 +10,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdcv_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
+# per-file extras.  attn: keep MFMA accumulators in arch VGPRs (gfx950's register file is unified) — the
+# softmax touches them with VALU every tile and the AGPR form costs ~250 v_accvgpr moves per key tile.
+EXTRA = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():
@@ -30,12 +33,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + hdrs):
+        if force or _stale(obj, [src, os.path.abspath(__file__)] + hdrs):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

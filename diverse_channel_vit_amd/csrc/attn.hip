@@ -76,8 +76,7 @@ __device__ __forceinline__ void zero_acc(f32x16& x) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char sK[64 * 128];
-    __shared__ __attribute__((aligned(16))) char sV[64 * 128];
+    __shared__ __attribute__((aligned(16))) char sKV[2][2][64 * 128];  // [buffer][K|V][64 keys x 128 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r32 = lane & 31;
     const int nqt = (a.N + 127) / 128;
     const int BH = a.B * a.H;
@@ -113,11 +112,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     Stage64 stK, stV;
     stage_load(stK, Kb, rs, 0, a.N, tid);
     stage_load(stV, Vb, rs, 0, a.N, tid);
-    stage_store(stK, sK, tid);
-    stage_store(stV, sV, tid);
+    stage_store(stK, sKV[0][0], tid);
+    stage_store(stV, sKV[0][1], tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
+        const char* sK = sKV[t & 1][0];
+        const char* sV = sKV[t & 1][1];
         if (t + 1 < nt) {
             stage_load(stK, Kb, rs, (t + 1) * 64, a.N, tid);
             stage_load(stV, Vb, rs, (t + 1) * 64, a.N, tid);
@@ -142,23 +143,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float alpha = exp2f((m - mx) * c);  // m = -inf on the first tile -> 0
         const float mc = mx * c;
-        m = mx;
         float rsum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = exp2f(s[kb][r] * c - mc);
+                float p = __builtin_amdgcn_exp2f(s[kb][r] * c - mc);
                 s[kb][r] = p;
                 rsum += p;
             }
-        l = l * alpha + rsum;
+        if (__any(mx > m)) {  // wave-uniform: some row's running maximum moved -> rescale what was accumulated under the old one
+            const float alpha = __builtin_amdgcn_exp2f((m - mx) * c);  // m = -inf on the first tile -> 0
+            l *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            m = mx;
+        }
+        l += rsum;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -167,10 +171,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_cols(sV, 32 * kb, ss, 32 * dt, lane), pf, o[dt]);
             }
-        __syncthreads();
-        if (t + 1 < nt) {
-            stage_store(stK, sK, tid);
-            stage_store(stV, sV, tid);
+        if (t + 1 < nt) {  // the other buffer was last read in iteration t-1, behind that iteration's barrier
+            stage_store(stK, sKV[(t + 1) & 1][0], tid);
+            stage_store(stV, sKV[(t + 1) & 1][1], tid);
         }
         __syncthreads();
     }
@@ -213,8 +216,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char sK[64 * 128];
-    __shared__ __attribute__((aligned(16))) char sV[64 * 128];
+    __shared__ __attribute__((aligned(16))) char sKV[2][2][64 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r32 = lane & 31;
     const int nqt = (a.N + 127) / 128;
     const int BH = a.B * a.H;
@@ -256,11 +258,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     Stage64 stK, stV;
     stage_load(stK, Kb, rs, 0, a.N, tid);
     stage_load(stV, Vb, rs, 0, a.N, tid);
-    stage_store(stK, sK, tid);
-    stage_store(stV, sV, tid);
+    stage_store(stK, sKV[0][0], tid);
+    stage_store(stV, sKV[0][1], tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
+        const char* sK = sKV[t & 1][0];
+        const char* sV = sKV[t & 1][1];
         if (t + 1 < nt) {
             stage_load(stK, Kb, rs, (t + 1) * 64, a.N, tid);
             stage_load(stV, Vb, rs, (t + 1) * 64, a.N, tid);
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
             const bool tail = (t + 1) * 64 > a.N;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = exp2f(s[r] * c - lse2);
+                float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
                 if (tail && (t * 64 + 32 * kb + acc_row(r, h) >= a.N)) p = 0.f;
                 s[r] = p * (dp[r] - dlt);  // dS^T (the 1/sqrt(d) factor is applied once, to dQ)
             }
@@ -289,10 +293,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
                 for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(frag_cols(sK, 32 * kb, ss, 32 * dt, lane), dsf, dq[dt]);
             }
         }
-        __syncthreads();
         if (t + 1 < nt) {
-            stage_store(stK, sK, tid);
-            stage_store(stV, sV, tid);
+            stage_store(stK, sKV[(t + 1) & 1][0], tid);
+            stage_store(stV, sKV[(t + 1) & 1][1], tid);
         }
         __syncthreads();
     }
@@ -311,10 +314,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char sQ[64 * 128];
-    __shared__ __attribute__((aligned(16))) char sO[64 * 128];  // dO tile
-    __shared__ __attribute__((aligned(16))) float sL[64];       // LSE * log2e   (+inf for rows >= N)
-    __shared__ __attribute__((aligned(16))) float sD[64];       // delta
+    __shared__ __attribute__((aligned(16))) char sQO[2][2][64 * 128];  // [buffer][Q|dO][64 queries x 128 B]
+    __shared__ __attribute__((aligned(16))) float sLD[2][2][64];       // [buffer][LSE*log2e (+inf for rows >= N) | delta]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r32 = lane & 31;
     const int nkt = (a.N + 127) / 128;
     const int BH = a.B * a.H;
@@ -365,15 +366,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
     stage_load(stQ, Qb, rs, 0, a.N, tid);
     stage_load(stO, dOb, (size_t)D, 0, a.N, tid);
     load_stats(0);
-    stage_store(stQ, sQ, tid);
-    stage_store(stO, sO, tid);
+    stage_store(stQ, sQO[0][0], tid);
+    stage_store(stO, sQO[0][1], tid);
     if (tid < 64) {
-        sL[tid] = stL;
-        sD[tid] = stD;
+        sLD[0][0][tid] = stL;
+        sLD[0][1][tid] = stD;
     }
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
+        const char* sQ = sQO[t & 1][0];
+        const char* sO = sQO[t & 1][1];
+        const float* sL = sLD[t & 1][0];
+        const float* sD = sLD[t & 1][1];
         if (t + 1 < nt) {
             stage_load(stQ, Qb, rs, (t + 1) * 64, a.N, tid);
             stage_load(stO, dOb, (size_t)D, (t + 1) * 64, a.N, tid);
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(&sD[32 * qb + 8 * g + 4 * h]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float p = exp2f(s[4 * g + e] * c - l4[e]);
+                    float p = __builtin_amdgcn_exp2f(s[4 * g + e] * c - l4[e]);
                     s[4 * g + e] = p;
                     dp[4 * g + e] = p * (dp[4 * g + e] - d4[e]);
                 }
@@ -412,13 +417,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
                 }
             }
         }
-        __syncthreads();
         if (t + 1 < nt) {
-            stage_store(stQ, sQ, tid);
-            stage_store(stO, sO, tid);
+            stage_store(stQ, sQO[(t + 1) & 1][0], tid);
+            stage_store(stO, sQO[(t + 1) & 1][1], tid);
             if (tid < 64) {
-                sL[tid] = stL;
-                sD[tid] = stD;
+                sLD[(t + 1) & 1][0][tid] = stL;
+                sLD[(t + 1) & 1][1][tid] = stD;
             }
         }
         __syncthreads();

@@ -36,41 +36,97 @@ struct GemmNtArgs {
     int T, n;
 };
 
-__device__ __forceinline__ float gelu_exact(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7: far below the bf16 rounding of the outputs), sharing
+// e = exp(-z^2/2) with the Gaussian pdf of GELU'.
+__device__ __forceinline__ void gelu_parts(float z, float& cdf, float& e) {
+    const float x = fabsf(z) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+    e = __builtin_amdgcn_exp2f(-0.72134752044448170f * z * z);  // exp(-z^2/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, z));
+}
+__device__ __forceinline__ float gelu_exact(float z) {
+    float cdf, e;
+    gelu_parts(z, cdf, e);
+    return z * cdf;
+}
 __device__ __forceinline__ float gelu_grad(float z) {
-    float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
-    float pdf = 0.39894228040143268f * __expf(-0.5f * z * z);
-    return cdf + z * pdf;
+    float cdf, e;
+    gelu_parts(z, cdf, e);
+    return cdf + z * 0.39894228040143268f * e;
 }
 
+__device__ __forceinline__ uint4 pack8_bf16(const float* v) {
+    uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ void unpack8_bf16(uint4 u, float* v) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void load8_f32(const float* p, float* v) {
+    float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void store8_f32(float* p, const float* v) {
+    reinterpret_cast<float4*>(p)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// epilogue on 8 consecutive columns n..n+7 of row m (16-byte global accesses; N % 8 == 0)
 template <int EPI>
-__device__ __forceinline__ void epilogue_store(const GemmNtArgs& a, int m, int n, float v) {
+__device__ __forceinline__ void epilogue_store8(const GemmNtArgs& a, int m, int n, float* v) {
+    float bz[8];
     if constexpr (EPI == DCV_EPI_BIAS_BF16) {
-        ((bf16_t*)a.out)[(size_t)m * a.ldo + n] = (bf16_t)(v + a.bias[n]);
+        load8_f32(a.bias + n, bz);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bz[e];
+        *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
     } else if constexpr (EPI == DCV_EPI_BIAS_GELU_BF16) {
-        float z = v + a.bias[n];
-        bf16_t zb = (bf16_t)z;
-        ((bf16_t*)a.out)[(size_t)m * a.ldo + n] = zb;                       // pre-activation (saved for backward)
-        ((bf16_t*)a.out2)[(size_t)m * a.ldo2 + n] = (bf16_t)gelu_exact((float)zb);  // activation
+        load8_f32(a.bias + n, bz);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bz[e];
+        const uint4 zb = pack8_bf16(v);  // pre-activation, saved for backward
+        *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = zb;
+        unpack8_bf16(zb, v);             // activation of the ROUNDED pre-activation (what backward differentiates)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_exact(v[e]);
+        *reinterpret_cast<uint4*>((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n) = pack8_bf16(v);
     } else if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
-        // out = residual + acc + bias; the residual is read from aux when given (out-of-place keeps the
-        // layer input alive for the LayerNorm backward at no extra traffic), else updated in place
+        // out = residual + acc + bias; the residual is read from aux when given (out-of-place keeps the layer input
+        // alive for the LayerNorm backward at no extra traffic), else updated in place
         const float* rsd = a.aux ? (const float*)a.aux + (size_t)m * a.ldaux + n : (const float*)a.out + (size_t)m * a.ldo + n;
-        ((float*)a.out)[(size_t)m * a.ldo + n] = *rsd + v + a.bias[n];
+        float r8[8];
+        load8_f32(a.bias + n, bz);
+        load8_f32(rsd, r8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bz[e] + r8[e];
+        store8_f32((float*)a.out + (size_t)m * a.ldo + n, v);
     } else if constexpr (EPI == DCV_EPI_PLAIN_BF16) {
-        ((bf16_t*)a.out)[(size_t)m * a.ldo + n] = (bf16_t)v;
+        *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
     } else if constexpr (EPI == DCV_EPI_GELU_BWD_BF16) {
-        float z = (float)((const bf16_t*)a.aux)[(size_t)m * a.ldaux + n];
-        ((bf16_t*)a.out)[(size_t)m * a.ldo + n] = (bf16_t)(v * gelu_grad(z));
+        float z8[8];
+        unpack8_bf16(*reinterpret_cast<const uint4*>((const bf16_t*)a.aux + (size_t)m * a.ldaux + n), z8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad(z8[e]);
+        *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
     } else if constexpr (EPI == DCV_EPI_PATCH) {
         // row m = b*T + t ; token t = c*n + i  ->  x[b, 1+t, :] = conv + bias + E[c] + pos[1+i]
-        int b = m / a.T, t = m - b * a.T;
-        int c = t / a.n, i = t - c * a.n;
-        float y = v + a.bias[n];
-        if (a.out2) ((float*)a.out2)[(size_t)m * a.ldo2 + n] = y;  // pre-embedding tokens (ortho loss input)
-        float e = ((const float*)a.aux)[(size_t)c * a.ldaux + n];
-        float p = a.aux2[(size_t)(1 + i) * a.ldaux + n];
-        ((float*)a.out)[((size_t)b * (a.T + 1) + 1 + t) * a.ldo + n] = y + e + p;
+        const int b = m / a.T, t = m - b * a.T;
+        const int c = t / a.n, i = t - c * a.n;
+        float e8[8], p8[8];
+        load8_f32(a.bias + n, bz);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bz[e];
+        if (a.out2) store8_f32((float*)a.out2 + (size_t)m * a.ldo2 + n, v);  // pre-embedding tokens (ortho loss input)
+        load8_f32((const float*)a.aux + (size_t)c * a.ldaux + n, e8);
+        load8_f32(a.aux2 + (size_t)(1 + i) * a.ldaux + n, p8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += e8[e] + p8[e];
+        store8_f32((float*)a.out + ((size_t)b * (a.T + 1) + 1 + t) * a.ldo + n, v);
     }
 }
 
@@ -158,18 +214,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
         __syncthreads();
     }
 
+    // Epilogue: each wave transposes its 64x64 accumulator through a private, padded LDS slab (two 32-row halves)
+    // so that every lane owns 8 consecutive columns of a row: all global accesses are 16-byte and row-contiguous.
+    constexpr int EP_LD = 68;  // floats per slab row (272 B: 16-byte aligned, rows shifted by 4 banks)
+    float* ep = reinterpret_cast<float*>(&smem[0][0][0]) + wave * 32 * EP_LD;
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + r32;
-            if (n >= a.N) continue;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + acc_row(r, h);
-                if (m < a.M) epilogue_store<EPI>(a, m, n, acc[i][j][r]);
-            }
+            for (int r = 0; r < 16; ++r) ep[acc_row(r, h) * EP_LD + j * 32 + r32] = acc[i][j][r];
+        __syncthreads();
+        const int n = n0 + wn * 64 + ecol;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int row = pass * 8 + erow;
+            const int m = m0 + wm * 64 + i * 32 + row;
+            float v[8];
+            load8_f32(ep + row * EP_LD + ecol, v);
+            if (m < a.M && n < a.N) epilogue_store8<EPI>(a, m, n, v);
         }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -191,9 +258,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, r32 = lane & 31, li = lane & 15, g1 = (lane >> 4) & 1;
     const int tiles_q = (a.Q + 127) / 128;
-    int bid = blockIdx.x;
-    const int split = bid % a.splits;
-    bid /= a.splits;
+    // tile index fastest, splits outer, and an XCD gets a contiguous range of logical ids: the workgroups that
+    // stream the SAME rows of Y and X (one split, all output tiles) run together on one XCD and share them in its L2.
+    const int tiles = tiles_q * ((a.P + 127) / 128);
+    int bid = xcd_remap(blockIdx.x, tiles * a.splits);
+    const int split = bid / tiles;
+    bid -= split * tiles;
     const int tq = bid % tiles_q, tp = bid / tiles_q;
     const int p0 = tp * 128, q0 = tq * 128;
     const int m_begin = split * a.m_per_split;
@@ -313,8 +383,8 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
                            const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
                            const float* aux2, int T, int n, void* stream) {
     if (!A || !W || !out) return DCV_ERR_NULL;
-    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0) return DCV_ERR_SHAPE;
-    if ((lda % 8) || (ldw % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return DCV_ERR_ALIGN;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
+    if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
     GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n};
     const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     hipStream_t s = (hipStream_t)stream;
