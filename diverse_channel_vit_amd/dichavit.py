@@ -163,6 +163,8 @@ class ChannelVisionTransformer(_Holder):
             if cfg.block_type == "block_v2":
                 raise ValueError("block_type=block_v2 is experimental in the reference (SURVEY §2.1 #2) and not provided")
             raise ValueError(f"Unknown block type: {cfg.block_type}")
+        if _cfg_get(cfg, "dropout_tokens_hcs", "none") not in (None, "none"):
+            raise ValueError("dropout_tokens_hcs variants (dichavit.py:568-627) are not provided by the HIP path yet")
         if (_cfg_get(cfg, "drop_path_rate", 0.0) or 0.0) != 0.0:
             raise ValueError("drop_path_rate > 0 is not supported by the HIP path (all reference scripts use 0)")
         self.num_features = self.embed_dim = self.out_dim = embed_dim
