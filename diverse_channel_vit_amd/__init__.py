@@ -8,5 +8,6 @@ a CPU implementation: the first forward loads diverse_channel_vit_amd/libdcv_hip
 from .dichavit import DiChaViT, dichavit, proxy_loss  # noqa: F401
 from .dp import DataParallel  # noqa: F401
 from .optim import HipAdamW  # noqa: F401
+from .graph import GraphedTrainStep  # noqa: F401
 
-__all__ = ["DiChaViT", "dichavit", "proxy_loss", "DataParallel", "HipAdamW"]
+__all__ = ["DiChaViT", "dichavit", "proxy_loss", "DataParallel", "HipAdamW", "GraphedTrainStep"]

@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;  // gemm_tn K-tile (gemm_nt streams NT_BK = 32 stages)
 
 struct GemmNtArgs {
     const bf16_t* A;
@@ -76,17 +76,39 @@ __device__ __forceinline__ void store8_f32(float* p, const float* v) {
     reinterpret_cast<float4*>(p)[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-// epilogue on 8 consecutive columns n..n+7 of row m (16-byte global accesses; N % 8 == 0)
+// Epilogue on 8 consecutive columns n..n+7 of row m (16-byte global accesses; N % 8 == 0), split in two so that the
+// auxiliary global loads of all passes are in flight together before any of them is consumed:
+//   epi_aux8   : loads what the epilogue needs from global memory (residual / saved pre-activation / embedding rows)
+//                — (m, n) are clamped by the caller, so it needs no predicate;
+//   epi_store8 : adds the bias slice (staged in LDS), applies the fused op and stores (caller predicates).
 template <int EPI>
-__device__ __forceinline__ void epilogue_store8(const GemmNtArgs& a, int m, int n, float* v) {
-    float bz[8];
+__device__ __forceinline__ void epi_aux8(const GemmNtArgs& a, int m, int n, float* x) {
+    if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
+        // residual is read from aux when given (out-of-place keeps the layer input alive for the LayerNorm backward
+        // at no extra traffic), else the output is updated in place
+        const float* rsd = a.aux ? (const float*)a.aux + (size_t)m * a.ldaux + n : (const float*)a.out + (size_t)m * a.ldo + n;
+        load8_f32(rsd, x);
+    } else if constexpr (EPI == DCV_EPI_GELU_BWD_BF16) {
+        unpack8_bf16(*reinterpret_cast<const uint4*>((const bf16_t*)a.aux + (size_t)m * a.ldaux + n), x);
+    } else if constexpr (EPI == DCV_EPI_PATCH) {
+        // row m = b*T + t ; token t = c*n + i  ->  channel_embed[c] + pos[1+i]
+        const int b = m / a.T, t = m - b * a.T;
+        const int c = t / a.n, i = t - c * a.n;
+        float p8[8];
+        load8_f32((const float*)a.aux + (size_t)c * a.ldaux + n, x);
+        load8_f32(a.aux2 + (size_t)(1 + i) * a.ldaux + n, p8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += p8[e];
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, float* v, const float* x, const float* bz) {
     if constexpr (EPI == DCV_EPI_BIAS_BF16) {
-        load8_f32(a.bias + n, bz);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bz[e];
         *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
     } else if constexpr (EPI == DCV_EPI_BIAS_GELU_BF16) {
-        load8_f32(a.bias + n, bz);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bz[e];
         const uint4 zb = pack8_bf16(v);  // pre-activation, saved for backward
@@ -96,77 +118,102 @@ __device__ __forceinline__ void epilogue_store8(const GemmNtArgs& a, int m, int 
         for (int e = 0; e < 8; ++e) v[e] = gelu_exact(v[e]);
         *reinterpret_cast<uint4*>((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n) = pack8_bf16(v);
     } else if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
-        // out = residual + acc + bias; the residual is read from aux when given (out-of-place keeps the layer input
-        // alive for the LayerNorm backward at no extra traffic), else updated in place
-        const float* rsd = a.aux ? (const float*)a.aux + (size_t)m * a.ldaux + n : (const float*)a.out + (size_t)m * a.ldo + n;
-        float r8[8];
-        load8_f32(a.bias + n, bz);
-        load8_f32(rsd, r8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bz[e] + r8[e];
+        for (int e = 0; e < 8; ++e) v[e] += bz[e] + x[e];
         store8_f32((float*)a.out + (size_t)m * a.ldo + n, v);
     } else if constexpr (EPI == DCV_EPI_PLAIN_BF16) {
         *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
     } else if constexpr (EPI == DCV_EPI_GELU_BWD_BF16) {
-        float z8[8];
-        unpack8_bf16(*reinterpret_cast<const uint4*>((const bf16_t*)a.aux + (size_t)m * a.ldaux + n), z8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad(z8[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad(x[e]);
         *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
     } else if constexpr (EPI == DCV_EPI_PATCH) {
-        // row m = b*T + t ; token t = c*n + i  ->  x[b, 1+t, :] = conv + bias + E[c] + pos[1+i]
         const int b = m / a.T, t = m - b * a.T;
-        const int c = t / a.n, i = t - c * a.n;
-        float e8[8], p8[8];
-        load8_f32(a.bias + n, bz);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bz[e];
         if (a.out2) store8_f32((float*)a.out2 + (size_t)m * a.ldo2 + n, v);  // pre-embedding tokens (ortho loss input)
-        load8_f32((const float*)a.aux + (size_t)c * a.ldaux + n, e8);
-        load8_f32(a.aux2 + (size_t)(1 + i) * a.ldaux + n, p8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += e8[e] + p8[e];
+        for (int e = 0; e < 8; ++e) v[e] += x[e];
         store8_f32((float*)a.out + ((size_t)b * (a.T + 1) + 1 + t) * a.ldo + n, v);
     }
 }
 
+// Issued through inline asm on purpose: hipcc then neither counts it in its own vmcnt bookkeeping nor fences the
+// following ds_reads with vmcnt(0) (which it does for the builtin and which would serialise the ring); the
+// kernel waits with hand-counted s_waitcnt vmcnt(N) + a raw s_barrier.  M0 (the LDS base) is saved and restored
+// inside the statement (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void glds16(const bf16_t* g, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_wave_base)
+        : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
+// gemm_nt geometry: 256 x 128 output tile, 8 waves as 4 (M) x 2 (N), each wave 64 x 64 = 2 x 2 MFMA 32x32x16 tiles.
+// Measured on MI355X: these short-K GEMMs (K = 384..1536) are bound by the rate at which a CU can pull operand bytes
+// through L2 into LDS (about 8 TB/s chip-wide with full 128-byte lines, half of that with 64-byte pieces), not by
+// MFMA issue: so (1) the tile is large (85 FLOP per operand byte vs 64 for 128 x 128), (2) every DMA instruction
+// fetches 8 rows x 128 contiguous bytes = whole cache lines (K is streamed in 64-wide stages), and (3) two of the three
+// 48 KB ring stages (96 KB per CU) are always in flight behind a counted vmcnt.
+constexpr int NT_BM = 256, NT_BN = 128, NT_BK = 64, NT_STAGES = 3;
+constexpr int NT_A_BYTES = NT_BM * NT_BK * 2, NT_W_BYTES = NT_BN * NT_BK * 2, NT_STAGE_BYTES = NT_A_BYTES + NT_W_BYTES;  // 48 KB
+
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[2][2][BM * BK * 2];  // [buf][A|W][16 KB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
+    // ONE shared array (a second __shared__ object can make hipcc drain vmcnt before every ds_read): 144 KB
+    __shared__ __attribute__((aligned(16))) char smem[NT_STAGES * NT_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, r32 = lane & 31;
-    const int tiles_n = (a.N + BN - 1) / BN;
-    const int tiles_m = (a.M + BM - 1) / BM;
+    const int tiles_n = (a.N + NT_BN - 1) / NT_BN;
+    const int tiles_m = (a.M + NT_BM - 1) / NT_BM;
     const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * NT_BM, n0 = tn * NT_BN;
 
-    // staging assignment: 4 chunks of 16 B per operand per thread
+    // Stage image: [rows][64 k] bf16 = 128-byte rows of 8 chunks; physical chunk = logical ^ swz64(row) (conflict-free
+    // ds_read_b128).  One DMA instruction = 8 rows x 128 B = 1 KiB (lane -> row lane>>3, physical chunk lane&7): the
+    // destination is linear, the permutation is applied to the per-lane SOURCE chunk.
+    // Wave w fills A rows [32w, 32w+32) (4 instructions) and W rows [16w, 16w+16) (2 instructions): 6 per stage.
     const bf16_t* gA[4];
-    const bf16_t* gW[4];
-    int soff[4];
+    const bf16_t* gW[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int q = tid + 256 * i, row = q >> 3, ch = q & 7;
-        int ra = min(m0 + row, a.M - 1), rw = min(n0 + row, a.N - 1);
-        gA[i] = a.A + (size_t)ra * a.lda + ch * 8;
-        gW[i] = a.W + (size_t)rw * a.ldw + ch * 8;
-        soff[i] = row * 128 + ((ch ^ swz64(row)) << 4);
-    }
-    uint4 ra[4], rw[4];
-    const int nk = a.K / BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const uint4*>(gA[i]);
-        rw[i] = *reinterpret_cast<const uint4*>(gW[i]);
+    for (int q = 0; q < 4; ++q) {
+        const int row = 32 * wave + 8 * q + (lane >> 3);
+        gA[q] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + (((lane & 7) ^ swz64(row)) * 8);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        lds_write128(smem[0][0], soff[i], ra[i]);
-        lds_write128(smem[0][1], soff[i], rw[i]);
+    for (int q = 0; q < 2; ++q) {
+        const int row = 16 * wave + 8 * q + (lane >> 3);
+        gW[q] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + (((lane & 7) ^ swz64(row)) * 8);
     }
-    __syncthreads();
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned dmaA = 32 * wave * 128, dmaW = NT_A_BYTES + 16 * wave * 128;  // wave-uniform byte offsets in a stage
+    const int nk = a.K / NT_BK;
+
+#define NT_ISSUE(kt_)                                                                     \
+    {                                                                                     \
+        const unsigned sb_ = smem_base + ((kt_) % NT_STAGES) * NT_STAGE_BYTES;            \
+        glds16(gA[0] + (kt_) * NT_BK, sb_ + dmaA);                                        \
+        glds16(gA[1] + (kt_) * NT_BK, sb_ + dmaA + 1024);                                 \
+        glds16(gA[2] + (kt_) * NT_BK, sb_ + dmaA + 2048);                                 \
+        glds16(gA[3] + (kt_) * NT_BK, sb_ + dmaA + 3072);                                 \
+        glds16(gW[0] + (kt_) * NT_BK, sb_ + dmaW);                                        \
+        glds16(gW[1] + (kt_) * NT_BK, sb_ + dmaW + 1024);                                 \
+    }
+
+    NT_ISSUE(0)
+    if (nk > 1) NT_ISSUE(1)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -177,48 +224,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int sw = swz64(r32);
-    const int rowA = (wm * 64 + r32) * 128, rowW = (wn * 64 + r32) * 128;
+    const int rowA = (wm * 64 + r32) * 128, rowW = NT_A_BYTES + (wn * 64 + r32) * 128;
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const uint4*>(gA[i] + (kt + 1) * BK);
-                rw[i] = *reinterpret_cast<const uint4*>(gW[i] + (kt + 1) * BK);
-            }
-        }
-        const char* sA = smem[cur][0];
-        const char* sW = smem[cur][1];
+        // my 6 DMAs of stage kt have landed once at most the next stage's 6 are outstanding
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone is done reading stage kt-1
+        if (kt + 2 < nk) NT_ISSUE(kt + 2)  // refills the buffer stage kt-1 used
+        const char* st = smem + (kt % NT_STAGES) * NT_STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int co = ((2 * ks + h) ^ sw) << 4;
             bf16x8 af[2], wf[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                af[i] = as_bf16x8(lds_read128(sA, rowA + i * 32 * 128 + co));
-                wf[i] = as_bf16x8(lds_read128(sW, rowW + i * 32 * 128 + co));
+                af[i] = as_bf16x8(lds_read128(st, rowA + i * 32 * 128 + co));
+                wf[i] = as_bf16x8(lds_read128(st, rowW + i * 32 * 128 + co));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
         }
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                lds_write128(smem[cur ^ 1][0], soff[i], ra[i]);
-                lds_write128(smem[cur ^ 1][1], soff[i], rw[i]);
-            }
-        }
-        __syncthreads();
     }
+#undef NT_ISSUE
+    __syncthreads();  // all stage reads done before the epilogue slabs overwrite the ring
 
     // Epilogue: each wave transposes its 64x64 accumulator through a private, padded LDS slab (two 32-row halves)
     // so that every lane owns 8 consecutive columns of a row: all global accesses are 16-byte and row-contiguous.
     constexpr int EP_LD = 68;  // floats per slab row (272 B: 16-byte aligned, rows shifted by 4 banks)
-    float* ep = reinterpret_cast<float*>(&smem[0][0][0]) + wave * 32 * EP_LD;
+    constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
+    constexpr bool HAS_AUX = (EPI == DCV_EPI_BIAS_RESID_F32) || (EPI == DCV_EPI_GELU_BWD_BF16) || (EPI == DCV_EPI_PATCH);
+    float* ep = reinterpret_cast<float*>(smem) + wave * 32 * EP_LD;      // 8.7 KB per wave, 69.6 KB in all
+    float* sbias = reinterpret_cast<float*>(smem + 8 * 32 * EP_LD * 4);  // 128 floats behind the slabs
+    if constexpr (HAS_BIAS) {
+        if (tid < NT_BN) sbias[tid] = a.bias[min(n0 + tid, a.N - 1)];
+    }
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    const int nn = n0 + wn * 64 + ecol;
+    const int nc = min(nn, a.N - 8);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -226,14 +271,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNtArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) ep[acc_row(r, h) * EP_LD + j * 32 + r32] = acc[i][j][r];
         __syncthreads();
-        const int n = n0 + wn * 64 + ecol;
+        // 32 rows x 8 column chunks = 256 items = 4 passes; all auxiliary global loads are issued before any is used
+        float v[4][8], x[4][8], bz[8];
+        if constexpr (HAS_BIAS) load8_f32(sbias + wn * 64 + ecol, bz);
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int row = pass * 8 + erow;
-            const int m = m0 + wm * 64 + i * 32 + row;
-            float v[8];
-            load8_f32(ep + row * EP_LD + ecol, v);
-            if (m < a.M && n < a.N) epilogue_store8<EPI>(a, m, n, v);
+        for (int q = 0; q < 4; ++q) {
+            const int row = q * 8 + erow;
+            const int mm = m0 + wm * 64 + i * 32 + row;
+            load8_f32(ep + row * EP_LD + ecol, v[q]);
+            if constexpr (HAS_AUX) epi_aux8<EPI>(a, min(mm, a.M - 1), nc, x[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mm = m0 + wm * 64 + i * 32 + q * 8 + erow;
+            if (mm < a.M && nn < a.N) epi_store8<EPI>(a, mm, nn, v[q], x[q], bz);
         }
         __syncthreads();
     }
@@ -383,34 +434,34 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
                            const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
                            const float* aux2, int T, int n, void* stream) {
     if (!A || !W || !out) return DCV_ERR_NULL;
-    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
     GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n};
-    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case DCV_EPI_BIAS_BF16:
             if (!bias) return DCV_ERR_NULL;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_BF16>, dim3(grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_BF16>, dim3(grid), dim3(512), 0, s, a);
             break;
         case DCV_EPI_BIAS_GELU_BF16:
             if (!bias || !out2) return DCV_ERR_NULL;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_GELU_BF16>, dim3(grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_GELU_BF16>, dim3(grid), dim3(512), 0, s, a);
             break;
         case DCV_EPI_BIAS_RESID_F32:
             if (!bias) return DCV_ERR_NULL;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_RESID_F32>, dim3(grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_RESID_F32>, dim3(grid), dim3(512), 0, s, a);
             break;
         case DCV_EPI_PLAIN_BF16:
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_PLAIN_BF16>, dim3(grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_PLAIN_BF16>, dim3(grid), dim3(512), 0, s, a);
             break;
         case DCV_EPI_GELU_BWD_BF16:
             if (!aux) return DCV_ERR_NULL;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_GELU_BWD_BF16>, dim3(grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_GELU_BWD_BF16>, dim3(grid), dim3(512), 0, s, a);
             break;
         case DCV_EPI_PATCH:
             if (!bias || !aux || !aux2 || T <= 0 || n <= 0 || (M % T) != 0 || (T % n) != 0) return DCV_ERR_SHAPE;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_PATCH>, dim3(grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_PATCH>, dim3(grid), dim3(512), 0, s, a);
             break;
         default:
             return DCV_ERR_UNSUPPORTED;
@@ -425,8 +476,9 @@ extern "C" int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, i
     if (M <= 0 || P <= 0 || Q <= 0 || (P % 8) || (Q % 8)) return DCV_ERR_SHAPE;
     if ((ldy % 8) || (ldx % 8) || ((uintptr_t)Y & 15) || ((uintptr_t)X & 15)) return DCV_ERR_ALIGN;
     const int tiles = ((P + 127) / 128) * ((Q + 127) / 128);
-    // ~2 workgroups per CU; every split a multiple of BK rows
-    int splits = (512 + tiles - 1) / tiles;
+    // one resident round: 2 workgroups per CU (64 KB LDS each) x 256 CUs = 512 slots; a 513th workgroup would run
+    // alone in a second round and double the launch time.  Every split is a multiple of BK rows.
+    int splits = 512 / tiles;
     int max_splits = (M + BK - 1) / BK;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

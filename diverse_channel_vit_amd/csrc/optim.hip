@@ -7,9 +7,16 @@
 
 namespace {
 
+// hyper (device, 8 floats) = {lr, beta1, beta2, eps, weight_decay, 1/bc1, 1/sqrt(bc2), grad_scale}: when non-null it
+// overrides the by-value arguments, so a HIP-graph replay of the step sees the current step count / learning rate.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n4, long n, float lr, float b1, float b2, float eps,
-                                                    float wd, float inv_bc1, float inv_sqrt_bc2, float gscale) {
+                                                    float wd, float inv_bc1, float inv_sqrt_bc2, float gscale,
+                                                    const float* __restrict__ hyper) {
+    if (hyper) {
+        lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4];
+        inv_bc1 = hyper[5]; inv_sqrt_bc2 = hyper[6]; gscale = hyper[7];
+    }
     const long stride = (long)gridDim.x * 256;
     const float decay = 1.f - lr * wd, step = lr * inv_bc1;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -95,7 +102,21 @@ extern "C" int dcv_adamw(float* p, const float* g, float* m, float* v, long n, f
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, lr, beta1, beta2, eps,
-                       weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+                       weight_decay, (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale, (const float*)nullptr);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_adamw_dyn(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, void* stream) {
+    if (!p || !g || !m || !v || !hyper_dev) return DCV_ERR_NULL;
+    if (n <= 0) return DCV_ERR_SHAPE;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return DCV_ERR_ALIGN;
+    long n4 = n / 4;
+    long grid = (n4 + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, n, 0.f, 0.f, 0.f, 0.f, 0.f,
+                       0.f, 0.f, 0.f, hyper_dev);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

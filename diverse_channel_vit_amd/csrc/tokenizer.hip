@@ -148,6 +148,14 @@ __global__ __launch_bounds__(256) void ortho_fwd_partial(const float* __restrict
     if (threadIdx.x == 0) atomicAdd(selfsq + bc, red_ss[0] + red_ss[1] + red_ss[2] + red_ss[3]);
 }
 
+// zero the two atomic accumulators (a kernel, not hipMemsetAsync: memset nodes did not replay correctly when the
+// step is captured into a HIP graph — the statistics went wrong from the second replay on)
+__global__ __launch_bounds__(256) void ortho_zero_kernel(float* __restrict__ S, long nS, float* __restrict__ selfsq, long nQ) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nS; i += stride) S[i] = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nQ; i += stride) selfsq[i] = 0.f;
+}
+
 // per image: tot = sum_c s_c ; stats = (pos_sum, neg_sum)
 __global__ __launch_bounds__(256) void ortho_fwd_final(const float* __restrict__ S, const float* __restrict__ selfsq,
                                                        float* __restrict__ tot, float* __restrict__ stats, int C, int D) {
@@ -266,8 +274,12 @@ extern "C" int dcv_ortho_fwd(const float* Y, float* S, float* selfsq, float* tot
     if (!Y || !S || !selfsq || !tot || !inv_norm || !stats) return DCV_ERR_NULL;
     if (B <= 0 || C <= 0 || n <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * OV) return DCV_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(S, 0, (size_t)B * C * D * sizeof(float), s) != hipSuccess) return DCV_ERR_LAUNCH;
-    if (hipMemsetAsync(selfsq, 0, (size_t)B * C * sizeof(float), s) != hipSuccess) return DCV_ERR_LAUNCH;
+    {
+        const long nS = (long)B * C * D, nQ = (long)B * C;
+        long zg = (nS + 255) / 256;
+        if (zg > 1024) zg = 1024;
+        hipLaunchKernelGGL(ortho_zero_kernel, dim3((unsigned)zg), dim3(256), 0, s, S, nS, selfsq, nQ);
+    }
     dim3 grid((n + ORTHO_CHUNK - 1) / ORTHO_CHUNK, B * C);
     hipLaunchKernelGGL(ortho_fwd_partial, grid, dim3(256), 0, s, Y, S, selfsq, inv_norm, C, n, D);
     hipLaunchKernelGGL(ortho_fwd_final, dim3(B), dim3(256), 0, s, S, selfsq, tot, stats, C, D);

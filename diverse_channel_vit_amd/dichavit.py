@@ -249,6 +249,7 @@ class DiChaViT(nn.Module):
         self._grad_arena = None
         self._dp = None  # set by diverse_channel_vit_amd.dp.DataParallel
         self._R_cache: Dict = {}
+        self._idx_cache: Dict = {}
         self.hcs_sampler = None  # optional callable(model, chunk_name, cur_channels) -> (picked ids, positions): pins the subset
 
     # ---------------------------------------------------------------------------------------
@@ -337,6 +338,15 @@ class DiChaViT(nn.Module):
     # ---------------------------------------------------------------------------------------
     # host-side pieces of PatchEmbedPerChannel.forward (dichavit.py:110-417)
     # ---------------------------------------------------------------------------------------
+    def _index_tensor(self, values, dtype, device):
+        """Small index lists live on the device once (no host->device copy per step; graph-capture safe)."""
+        key = (tuple(values), dtype, str(device))
+        t = self._idx_cache.get(key)
+        if t is None:
+            t = torch.tensor(list(values), dtype=dtype, device=device)
+            self._idx_cache[key] = t
+        return t
+
     def _sample_channels(self, chunk_name, cur_channels, channel_embed):
         """HCS sampling (dichavit.py:127-216).  Returns (sampled global ids, their positions in the chunk)."""
         pe = self.feature_extractor.patch_embed
@@ -592,7 +602,7 @@ class DiChaViT(nn.Module):
         cur_channels = list(pe.mapper[chunk_name])  # dichavit.py:120
         if Cin != len(cur_channels):
             raise ValueError(f"input has {Cin} channels but mapper['{chunk_name}'] lists {len(cur_channels)}")
-        ch_t = torch.tensor(cur_channels, device=x.device)
+        ch_t = self._index_tensor(cur_channels, torch.int64, x.device)
         channel_embed = pe.channel_embed(ch_t)  # [Cin, D]  :122
         idx = list(range(Cin))
         if self.training and pe.enable_sample:  # :127
@@ -607,7 +617,7 @@ class DiChaViT(nn.Module):
         lam_p = _cfg_get(cfg, "proxy_loss_lambda", 0) or 0
         want_ortho = bool(self.training and lam_o > 0)
         pos_tab = self._pos_table(C, n, Hi, Wi)
-        ch_idx_dev = torch.tensor(idx, dtype=torch.int32, device=x.device)
+        ch_idx_dev = self._index_tensor(idx, torch.int32, x.device)
         feat, stats = _EncoderFn.apply(self, ch_idx_dev, C, want_ortho, x, channel_embed, pos_tab, *self._enc_params)
         # --- regularisers (tiny tensors; models/loss_fn.py) ---
         extra = 0
@@ -616,7 +626,7 @@ class DiChaViT(nn.Module):
         if lam_p > 0 and (self.training or True):
             # the reference evaluates the proxy term in eval mode too and discards it; skip it there
             if self.training:
-                prox = pe.channel_emb_proxies[cur_channels]  # global ids  (:401)
+                prox = pe.channel_emb_proxies[self._index_tensor(cur_channels, torch.int64, x.device)]  # global ids (:401)
                 extra = extra + lam_p * _proxy_loss(prox, channel_embed, torch.eye(C, device=x.device), float(pe.channel_scale))
         out = self.classifer_head(feat)  # :855
         if self.training:

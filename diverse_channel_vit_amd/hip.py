@@ -33,6 +33,7 @@ _SIGS = {
     "dcv_ortho_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_ortho_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_adamw": ([_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
+    "dcv_adamw_dyn": ([_vp, _vp, _vp, _vp, _l, _vp, _vp], _i),
     "dcv_cast_bf16": ([_vp, _vp, _l, _vp], _i),
     "dcv_cast_transpose_bf16": ([_vp, _vp, _vp, _i, _i, _vp], _i),
 }
@@ -190,6 +191,10 @@ def ortho_bwd(Y, S, tot, inv_norm, coef, dY, B, Cc, n, D):
 
 def adamw(p, g, m, v, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
     _check(load().dcv_adamw(_p(p), _p(g), _p(m), _p(v), n, lr, b1, b2, eps, wd, step, grad_scale, _stream()), "dcv_adamw")
+
+
+def adamw_dyn(p, g, m, v, n, hyper_dev):
+    _check(load().dcv_adamw_dyn(_p(p), _p(g), _p(m), _p(v), n, _p(hyper_dev), _stream()), "dcv_adamw_dyn")
 
 
 def cast_bf16(src, dst, n):

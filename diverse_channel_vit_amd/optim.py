@@ -18,7 +18,7 @@ from . import hip
 
 
 class HipAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, model=None, capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         if len(self.param_groups) != 1:
@@ -26,6 +26,25 @@ class HipAdamW(torch.optim.Optimizer):
         self.model = model
         self._step = 0
         self._m = self._v = None
+        # capturable: the kernels read {lr, betas, eps, wd, bias corrections} from a device buffer that advance()
+        # rewrites before every step, so step() can live inside a captured HIP graph (graph.GraphedTrainStep)
+        self.capturable = capturable
+        self._hyper_dev = None
+        self._hyper_host = None
+
+    def advance(self):
+        """capturable mode: bump the step count and upload this step's scalars (async, current stream)."""
+        import math
+        grp = self.param_groups[0]
+        self._step += 1
+        b1, b2 = grp["betas"]
+        vals = [float(grp["lr"]), b1, b2, float(grp["eps"]), float(grp["weight_decay"]),
+                1.0 / (1.0 - b1 ** self._step), 1.0 / math.sqrt(1.0 - b2 ** self._step), 1.0]
+        if self._hyper_dev is None:
+            self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+            self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=grp["params"][0].device)
+        self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
+        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
 
     def _ensure_state(self):
         model = self.model
@@ -52,7 +71,11 @@ class HipAdamW(torch.optim.Optimizer):
         self._ensure_state()
         grp = self.param_groups[0]
         lr, (b1, b2), eps, wd = float(grp["lr"]), grp["betas"], float(grp["eps"]), float(grp["weight_decay"])
-        self._step += 1
+        if self.capturable:
+            if self._hyper_dev is None:
+                raise RuntimeError("capturable HipAdamW: call advance() before step()")
+        else:
+            self._step += 1
         step = self._step
         mine = {id(p) for p in grp["params"]}
         ga = model._grad_arena
@@ -63,7 +86,10 @@ class HipAdamW(torch.optim.Optimizer):
         done = set()
         if fused:
             n = model._enc_size
-            hip.adamw(model._arena, ga, self._m, self._v, n, lr, b1, b2, eps, wd, step, 1.0)
+            if self.capturable:
+                hip.adamw_dyn(model._arena, ga, self._m, self._v, n, self._hyper_dev)
+            else:
+                hip.adamw(model._arena, ga, self._m, self._v, n, lr, b1, b2, eps, wd, step, 1.0)
             done = {id(p) for p in enc}
         off = {id(p): o for p, o in zip(model._all_params, model._all_off)}
         for p in grp["params"]:
@@ -76,7 +102,10 @@ class HipAdamW(torch.optim.Optimizer):
             n = p.numel()
             if (o * 4) % 16 or g.data_ptr() % 16:
                 raise RuntimeError("unaligned parameter slot")
-            hip.adamw(model._arena[o:o + n], g, self._m[o:o + n], self._v[o:o + n], n, lr, b1, b2, eps, wd, step, 1.0)
+            if self.capturable:
+                hip.adamw_dyn(model._arena[o:o + n], g, self._m[o:o + n], self._v[o:o + n], n, self._hyper_dev)
+            else:
+                hip.adamw(model._arena[o:o + n], g, self._m[o:o + n], self._v[o:o + n], n, lr, b1, b2, eps, wd, step, 1.0)
         for p in grp["params"]:
             self.state[p]["step"] = step
         return loss

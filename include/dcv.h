@@ -88,6 +88,10 @@ int dcv_ortho_bwd(const float* Y, const float* S, const float* tot, const float*
 /* fused AdamW over a flat fp32 range; g is multiplied by grad_scale first (1/world for data parallel). */
 int dcv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, float grad_scale, void* stream);
+/* same update with the scalars read from device memory: hyper_dev[8] = {lr, beta1, beta2, eps, weight_decay,
+ * 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale}.  Lets a captured HIP graph of the step be replayed while the
+ * step count and the schedulers' lr / weight decay advance (the host rewrites the 32 bytes between replays). */
+int dcv_adamw_dyn(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, void* stream);
 /* bf16 operand copies of the parameter arena */
 int dcv_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* desc_dev: device int64 [n_desc][4] = {src offset, dst offset, R, C}; dst[C][R] = bf16(src[R][C]) */
