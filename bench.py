@@ -212,7 +212,9 @@ def main():
                     "frac": round(ach / 8000.0, 4), "traffic": None, "avg_launch_ms": round(per_launch_ms, 4), "launches_timed": len(rec)}
         imgs = args.batch * world * args.steps / dt
         line = {
-            "metric": "train images/sec, DiChaViT-S 8ch 224^2 bs=64/GPU", "value": round(imgs, 2), "unit": "images/sec",
+            "metric": ("train images/sec, DiChaViT-S 8ch 224^2 bs=64/GPU" if (args.arch, C, args.img, args.batch) == ("small", 8, 224, 64)
+                       else f"train images/sec, DiChaViT-{args.arch} {C}ch {args.img}^2 bs={args.batch}/GPU"),
+            "value": round(imgs, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"DiChaViT-{args.arch} {C}ch {args.img}x{args.img} P16 {args.classes} classes, train step "

@@ -14,6 +14,7 @@
 //   attn_bwd_dkdv : WG = 4 waves x 32 keys, loops over 64-query tiles; S = Q . K^T (key on the lane),
 //                   dP = dO . V^T, dV^T += dO^T . P, dK^T += Q^T . dS.   No atomics anywhere: results
 //                   are bitwise reproducible.
+#include <type_traits>
 #include "dcv_common.hpp"
 #include "../../include/dcv.h"
 
@@ -74,10 +75,64 @@ __device__ __forceinline__ void zero_acc(f32x16& x) {
     for (int r = 0; r < 16; ++r) x[r] = 0.f;
 }
 
+// Per-lane LDS byte offsets computed ONCE per kernel; every fragment address in the tile loops is then
+// lane_offset + compile-time constant (buffer, tile, 32-row block, k-step), which the compiler folds into the
+// ds_read `offset:` immediate — the loops carry no address arithmetic.
+struct LaneOffs {
+    int rows[4];     // frag_rows: row r32 of a 32-row block, k-step ks      (+ 4096 per 32-row block)
+    int cols[2][2];  // frag_cols: [dt][lo|hi] for rows 4h + (li>>2) (+8)    (+ 4096 per 32-row block, + 2048 per k-step)
+};
+__device__ __forceinline__ LaneOffs lane_offs(int lane) {
+    LaneOffs o;
+    const int h = lane >> 5, r32 = lane & 31, g1 = (lane >> 4) & 1, li = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o.rows[ks] = r32 * 128 + (((2 * ks + h) ^ swz64(r32)) << 4);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int row = 4 * h + (li >> 2), col = 32 * dt + 16 * g1 + 4 * (li & 3);
+        o.cols[dt][0] = lds64_off(row, col);
+        o.cols[dt][1] = lds64_off(row + 8, col);
+    }
+    return o;
+}
+// tile: byte offset of the [64][64] tile inside `base`; blk: 32-row block (0/1)
+__device__ __forceinline__ bf16x8 frag_rows_o(const char* base, const LaneOffs& o, int tile, int blk, int ks) {
+    return as_bf16x8(lds_read128(base, o.rows[ks] + tile + blk * 4096));
+}
+__device__ __forceinline__ bf16x8 frag_cols_o(const char* base, const LaneOffs& o, int tile, int blk, int s, int dt) {
+    const int c = tile + blk * 4096 + s * 2048;
+    return join4(lds_tr_read(base, o.cols[dt][0] + c), lds_tr_read(base, o.cols[dt][1] + c));
+}
+
 // ------------------------------------------------------------------------------------------------
+// K/V ring: 4 stages x (8 KB K + 8 KB V), filled by LDS-DMA three tiles ahead (48 KB in flight per workgroup).
+// A register-staged single-tile prefetch left every key tile waiting ~1.5 us for its loads (measured: 3400 cycles
+// per tile for 512 cycles of MFMA).  Each wave issues 4 DMA instructions per stage: rows [16w,16w+16) of K and of V.
+constexpr int KV_STAGES = 4, KV_STAGE_BYTES = 16384;
+
+struct KvDma {
+    const bf16_t* kbase;  // K rows of this (batch, head)
+    const bf16_t* vbase;
+    size_t rs;            // row stride (elements)
+    int N, rowl;          // rowl: this lane's tile row in the wave's first 8-row piece (second piece: +8)
+    int lc8[2];           // per piece: (logical chunk this lane must fetch for its physical slot) * 8 elements
+    unsigned smem_base, wave_off;
+};
+__device__ __forceinline__ void kv_issue(const KvDma& d, int t) {
+    const unsigned sb = d.smem_base + (t & (KV_STAGES - 1)) * KV_STAGE_BYTES + d.wave_off;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = min(t * 64 + d.rowl + 8 * j, d.N - 1);  // keys >= N: clamp (masked by the caller)
+        const size_t off = (size_t)row * d.rs + d.lc8[j];
+        glds16(d.kbase + off, sb + j * 1024);
+        glds16(d.vbase + off, sb + 8192 + j * 1024);
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char sKV[2][2][64 * 128];  // [buffer][K|V][64 keys x 128 B]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, r32 = lane & 31;
+    __shared__ __attribute__((aligned(16))) char sKV[KV_STAGES * KV_STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nqt = (a.N + 127) / 128;
     const int BH = a.B * a.H;
     int bh, qt;
@@ -93,14 +148,31 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const int D = a.H * 64;
     const size_t rs = (size_t)3 * D;  // qkv row stride (elements)
     const bf16_t* Qb = a.qkv + (size_t)b * a.N * rs + hh * 64;
-    const bf16_t* Kb = Qb + D;
-    const bf16_t* Vb = Qb + 2 * D;
+
+    const int nt = (a.N + 63) / 64;
+    KvDma dma;
+    dma.kbase = Qb + D;
+    dma.vbase = Qb + 2 * D;
+    dma.rs = rs;
+    dma.N = a.N;
+    dma.rowl = 16 * wave + (lane >> 3);
+    dma.lc8[0] = ((lane & 7) ^ swz64(dma.rowl)) * 8;
+    dma.lc8[1] = ((lane & 7) ^ swz64(dma.rowl + 8)) * 8;
+    dma.smem_base = __builtin_amdgcn_readfirstlane(lds_addr(sKV));
+    dma.wave_off = 16 * wave * 128;
+    for (int st = 0; st < KV_STAGES - 1; ++st)
+        if (st < nt) kv_issue(dma, st);
 
     const int q = qt * 128 + wave * 32 + r32;  // this lane's query row
     const int qc = min(q, a.N - 1);
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Qb + (size_t)qc * rs + 16 * ks + 8 * h));
+    // consume the fragments here so that hipcc's own wait for these loads sits BEFORE the tile loop: inside it, its
+    // vmcnt(0) (it does not know about the asm-issued DMAs) would drain the K/V ring on every tile
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]));
+    const LaneOffs lo = lane_offs(lane);
 
     f32x16 o[2];
     zero_acc(o[0]);
@@ -108,29 +180,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     float m = -INFINITY, l = 0.f;
     const float c = a.scale * LOG2E;
 
-    const int nt = (a.N + 63) / 64;
-    Stage64 stK, stV;
-    stage_load(stK, Kb, rs, 0, a.N, tid);
-    stage_load(stV, Vb, rs, 0, a.N, tid);
-    stage_store(stK, sKV[0][0], tid);
-    stage_store(stV, sKV[0][1], tid);
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const char* sK = sKV[t & 1][0];
-        const char* sV = sKV[t & 1][1];
-        if (t + 1 < nt) {
-            stage_load(stK, Kb, rs, (t + 1) * 64, a.N, tid);
-            stage_load(stV, Vb, rs, (t + 1) * 64, a.N, tid);
+    // one key tile; MASKED is compile-time so only the last, partial tile carries the masking code
+    auto tile = [&](auto MASKED, int t) {
+        // my 4 DMAs of stage t have landed once at most the younger stages' are outstanding
+        const int rem = nt - 1 - t;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's stage t landed; everyone is done reading stage t-1
+        if (t + KV_STAGES - 1 < nt) kv_issue(dma, t + KV_STAGES - 1);
+        LaneOffs k = lo;  // this stage's addresses: 8 integer adds per tile, the rest are immediates
+        const int so = (t & (KV_STAGES - 1)) * KV_STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) k.rows[i] += so;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            k.cols[i][0] += so + 8192;
+            k.cols[i][1] += so + 8192;
         }
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             zero_acc(s[kb]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows(sK, 32 * kb, r32, h, ks), qf[ks], s[kb]);
+            for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows_o(sKV, k, 0, kb, ks), qf[ks], s[kb]);
         }
-        if ((t + 1) * 64 > a.N) {  // tail tile: keys >= N do not exist
+        if constexpr (decltype(MASKED)::value) {  // keys >= N do not exist
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -169,14 +244,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
             for (int ss = 0; ss < 2; ++ss) {
                 bf16x8 pf = acc_to_frag(s[kb], ss);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_cols(sV, 32 * kb, ss, 32 * dt, lane), pf, o[dt]);
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_cols_o(sKV, k, 0, kb, ss, dt), pf, o[dt]);
             }
-        if (t + 1 < nt) {  // the other buffer was last read in iteration t-1, behind that iteration's barrier
-            stage_store(stK, sKV[(t + 1) & 1][0], tid);
-            stage_store(stV, sKV[(t + 1) & 1][1], tid);
-        }
-        __syncthreads();
-    }
+    };
+    using No = std::integral_constant<bool, false>;
+    using Yes = std::integral_constant<bool, true>;
+    const int nfull = a.N / 64;  // full tiles first, then at most one masked tail tile
+    for (int t = 0; t < nfull; ++t) tile(No{}, t);
+    if (nfull < nt) tile(Yes{}, nfull);
+
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
     if (q < a.N) {

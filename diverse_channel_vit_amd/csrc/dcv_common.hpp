@@ -126,6 +126,28 @@ __device__ __forceinline__ uint2 pack4_bf16(float a, float b, float c, float d) 
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 
+// ---- LDS-DMA (global_load_lds_dwordx4): destination is wave-uniform base + lane*16; any swizzle is applied to the
+// per-lane SOURCE address (linear destination + permuted source + the same permutation on the read).
+// Issued through inline asm on purpose: hipcc then neither counts it in its own vmcnt bookkeeping nor fences the
+// following ds_reads with vmcnt(0) (which it does for the builtin and which would serialise the ring); the
+// kernel waits with hand-counted s_waitcnt vmcnt(N) + a raw s_barrier.  M0 (the LDS base) is saved and restored
+// inside the statement (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void glds16(const bf16_t* g, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(lds_wave_base)
+        : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+
 // XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch, speed only).  Gives each
 // XCD a contiguous range of logical ids.  Bijective for any n.
 __device__ __forceinline__ int xcd_remap(int bid, int n) {

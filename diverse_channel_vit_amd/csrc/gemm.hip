@@ -138,26 +138,6 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
     }
 }
 
-// Issued through inline asm on purpose: hipcc then neither counts it in its own vmcnt bookkeeping nor fences the
-// following ds_reads with vmcnt(0) (which it does for the builtin and which would serialise the ring); the
-// kernel waits with hand-counted s_waitcnt vmcnt(N) + a raw s_barrier.  M0 (the LDS base) is saved and restored
-// inside the statement (cdna_hip_programming.md §5.7).
-__device__ __forceinline__ void glds16(const bf16_t* g, unsigned lds_wave_base) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(g), "s"(lds_wave_base)
-        : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
-}
-
 // gemm_nt geometry: 256 x 128 output tile, 8 waves as 4 (M) x 2 (N), each wave 64 x 64 = 2 x 2 MFMA 32x32x16 tiles.
 // Measured on MI355X: these short-K GEMMs (K = 384..1536) are bound by the rate at which a CU can pull operand bytes
 // through L2 into LDS (about 8 TB/s chip-wide with full 128-byte lines, half of that with 64-byte pieces), not by

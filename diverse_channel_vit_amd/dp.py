@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 
 class DataParallel:
-    def __init__(self, model, process_group=None, min_bucket_bytes: int = 4 << 20):
+    def __init__(self, model, process_group=None, min_bucket_bytes: int = 4 << 20, force_collectives: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.model = model
@@ -31,6 +31,7 @@ class DataParallel:
         self.world = dist.get_world_size(process_group)
         self.backend = dist.get_backend(process_group)
         self._avg = self.backend == "nccl"  # RCCL has a native AVG; gloo sums and we scale
+        self._force = force_collectives     # issue the collectives even at world_size 1 (single-GPU plumbing tests)
         self._works: List = []
         self._scaled: List[torch.Tensor] = []
         self._pending = None  # (arena, lo, hi) waiting to be merged into a bucket of >= min_bucket_bytes
@@ -59,7 +60,7 @@ class DataParallel:
         self._reduce(arena[lo:hi])
 
     def _reduce(self, t: torch.Tensor) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))

@@ -293,7 +293,19 @@ def case_curve_jumpcp(dichavit, loss_fn):
     _curve(dichavit, "curve100_jumpcp_s", base_cfg(), 8, 224, 161, 2, 81, 100, 4)
 
 
-CASES = dict(loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
+def case_schedules(dichavit, loss_fn):
+    """utils.cosine_scheduler (utils.py:563-574): the weight-decay schedule of trainer.py:217-228."""
+    import utils as ref_utils
+    arrays, meta = {}, {"cases": []}
+    for k, kw in enumerate([dict(base_value=0.04, final_value=0.4, epochs=10, niter_per_ep=7),
+                            dict(base_value=0.04, final_value=0.4, epochs=6, niter_per_ep=5, warmup_epochs=2, start_warmup_value=0.01),
+                            dict(base_value=1.0, final_value=0.0, epochs=3, niter_per_ep=1)]):
+        arrays[f"wd_{k}"] = np.asarray(ref_utils.cosine_scheduler(**kw), dtype=np.float64)
+        meta["cases"].append(kw)
+    save("schedules", meta, arrays)
+
+
+CASES = dict(schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
              chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp)
 
 if __name__ == "__main__":

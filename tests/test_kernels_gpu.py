@@ -259,3 +259,30 @@ def test_adamw_and_casts(hip):
     hip.cast_transpose_bf16(src, out, desc, 2, 18 * 6)
     assert torch.equal(out[:1152 * 384].reshape(384, 1152), src[:1152 * 384].reshape(1152, 384).t().to(torch.bfloat16))
     assert torch.equal(out[1152 * 384:].reshape(70, 100), src[1152 * 384:].reshape(100, 70).t().to(torch.bfloat16))
+
+
+def test_attention_long_sequence_base_heads(hip):
+    """BASELINE config 5 shape class: 64 channels x 196 patches + CLS = 12 545 tokens, 12 heads (two of them here to
+    keep the N x N fp32 reference at 1.3 GB).  Forward and backward against the materialised softmax."""
+    B, N, H = 1, 12545, 2
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = _bf(B, N, 3 * D, scale=1.0, seed=3)
+    o = torch.empty(B, N, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    hip.attn_fwd(qkv, o, lse, B, N, H, 64, scale)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, B, N, H, scale)
+    _close(o, o_ref, 2e-2, 5e-3, "attn O long")
+    _close(lse, lse_ref, 1e-4, 2e-3, "attn LSE long")
+    dO = _bf(B, N, D, seed=7)
+    o_ref.backward(dO.float())
+    dqkv = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device="cuda")
+    delta = torch.empty(B, H, N, device="cuda")
+    hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, scale)
+    g = qr.grad.reshape(B, N, 3, D)
+    d = dqkv.float().reshape(B, N, 3, D)
+    for i, nm in enumerate(["dQ", "dK", "dV"]):
+        ref = g[:, :, i]
+        rel = (d[:, :, i] - ref).norm().item() / ref.norm().item()
+        assert rel <= 2e-2, (nm, rel)

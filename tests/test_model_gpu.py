@@ -297,3 +297,67 @@ def test_graphed_step_matches_eager(gpu_device):
     we, wg = runs["eager"][1], runs["graph"][1]
     assert (we - wg).abs().max().item() <= 2e-4, (we - wg).abs().max().item()
     assert lg[-1] < lg[0]
+
+
+def test_dp_reducer_on_rccl_single_gpu(gpu_device):
+    """The data-parallel path of bench.py (dp.DataParallel: per-layer arena buckets all-reduced from inside the
+    backward, hooks for the parameters outside the encoder, HipAdamW.finalize) on the real RCCL backend.  Only one
+    GPU is available to tests, so the group has world_size 1 and the collectives are forced: this checks the
+    plumbing (async all-reduce of arena slices issued from the autograd thread, AVG op, stream waits) — gradients
+    must be identical to the single-process run.  Multi-rank arithmetic is covered by tests/test_dp_gloo.py."""
+    import os
+    import torch.distributed as dist
+    import diverse_channel_vit_amd as dcv
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29613")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu_device)
+    try:
+        meta, _ = load_golden("so2sat_s")
+        x, y = orc.make_batch(5, 4, 18, 32, 17)
+        x, y = x.to(gpu_device), y.to(gpu_device)
+        grads = {}
+        for mode in ("plain", "dp"):
+            model, _ = build(meta, gpu_device)
+            if mode == "dp":
+                model._ensure_arena(gpu_device)
+                dp = dcv.DataParallel(model, min_bucket_bytes=1 << 20, force_collectives=True)
+                dp.broadcast_parameters(0)
+                dp.hook_misc_params()
+            opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, model=model)
+            opt.zero_grad()
+            out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            (torch.nn.functional.cross_entropy(out, y) + extra).backward()
+            if mode == "dp":
+                assert dp.buckets_launched >= 8  # 12 blocks (7 MB each) merged/kept + tokeniser + final norm + misc params
+                dp.finalize()
+            grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            opt.step()
+        for k, g in grads["plain"].items():
+            ref = g.abs().max().item()
+            assert (grads["dp"][k] - g).abs().max().item() <= 1e-3 * ref + 1e-9, k
+    finally:
+        dist.destroy_process_group()
+
+
+def test_base_width_train_step(gpu_device):
+    """DiChaViT-Base dimensions (D = 768, 12 heads, MLP 3072; BASELINE config 5's architecture) on a small image:
+    one training step against the oracle — exercises every kernel at the wider layout (LN/ortho lanes, GEMM N tiles
+    that are not multiples of the tile, 12-head attention)."""
+    cfg = dict(name="dichavit", pretrained_model_name="base", patch_size=16, temperature=0.07, learnable_temp=False,
+               enable_sample=False, use_channelvit_channels=True, orthogonal_channel_emb_init=True, dropout_tokens_hcs="none",
+               freeze_channel_emb=False, block_type="block", hcs_sampling="none", hcs_sampling_temp=0.1, proxy_loss_lambda=0.001,
+               ortho_loss_v1_lambda=0.001, drop_path_rate=0.0, gamma_s=1.0, gamma_d=4.0, reverse_pos_pairs=True, use_square=False)
+    meta = dict(cfg=cfg, mapper={"train": list(range(5))}, n_channels=5, img=64, num_classes=11, seed=91, B=2)
+    model, _ = build(meta, gpu_device)
+    x, y = orc.make_batch(92, 2, 5, 64, 11)
+    out, extra = model(x.to(gpu_device), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    loss = torch.nn.functional.cross_entropy(out, y.to(gpu_device)) + extra
+    loss.backward()
+    sd_ref, loss_ref, extra_ref, out_ref = oracle_grads(meta, x, y, list(range(5)), list(range(5)))
+    assert (out.detach().cpu().double() - out_ref).abs().max().item() <= 3e-2 * out_ref.abs().max().item()
+    # D = 768 / K = 3072 reductions of bf16 operands: twice the width of S, so the loss tolerance is 2e-2 here
+    assert abs(loss.item() - loss_ref) <= 2e-2
+    worst = check_grads(model, sd_ref)
+    print(f"base width: loss {loss.item():.6f} (oracle {loss_ref:.6f}) worst grad rel err {worst}")
