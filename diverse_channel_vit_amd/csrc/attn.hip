@@ -108,7 +108,13 @@ __device__ __forceinline__ bf16x8 frag_cols_o(const char* base, const LaneOffs& 
 // K/V ring: 4 stages x (8 KB K + 8 KB V), filled by LDS-DMA three tiles ahead (48 KB in flight per workgroup).
 // A register-staged single-tile prefetch left every key tile waiting ~1.5 us for its loads (measured: 3400 cycles
 // per tile for 512 cycles of MFMA).  Each wave issues 4 DMA instructions per stage: rows [16w,16w+16) of K and of V.
-constexpr int KV_STAGES = 4, KV_STAGE_BYTES = 16384;
+#ifndef DCV_ABL
+#define DCV_ABL 0
+#endif
+#ifndef DCV_KV_STAGES
+#define DCV_KV_STAGES 4
+#endif
+constexpr int KV_STAGES = DCV_KV_STAGES, KV_STAGE_BYTES = 16384;
 
 struct KvDma {
     const bf16_t* kbase;  // K rows of this (batch, head)
@@ -119,7 +125,7 @@ struct KvDma {
     unsigned smem_base, wave_off;
 };
 __device__ __forceinline__ void kv_issue(const KvDma& d, int t) {
-    const unsigned sb = d.smem_base + (t & (KV_STAGES - 1)) * KV_STAGE_BYTES + d.wave_off;
+    const unsigned sb = d.smem_base + (t % KV_STAGES) * KV_STAGE_BYTES + d.wave_off;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = min(t * 64 + d.rowl + 8 * j, d.N - 1);  // keys >= N: clamp (masked by the caller)
@@ -184,13 +190,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     auto tile = [&](auto MASKED, int t) {
         // my 4 DMAs of stage t have landed once at most the younger stages' are outstanding
         const int rem = nt - 1 - t;
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (KV_STAGES >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone's stage t landed; everyone is done reading stage t-1
         if (t + KV_STAGES - 1 < nt) kv_issue(dma, t + KV_STAGES - 1);
         LaneOffs k = lo;  // this stage's addresses: 8 integer adds per tile, the rest are immediates
-        const int so = (t & (KV_STAGES - 1)) * KV_STAGE_BYTES;
+        const int so = (t % KV_STAGES) * KV_STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) k.rows[i] += so;
 #pragma unroll
@@ -212,6 +218,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r)
                     if (t * 64 + 32 * kb + acc_row(r, h) >= a.N) s[kb][r] = -INFINITY;
         }
+#if DCV_ABL == 1  // ablation (timing only): no softmax arithmetic
+        float mx = m, rsum = 0.f;
+#else
         float mx = m;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -237,14 +246,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             m = mx;
         }
+#endif
         l += rsum;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 bf16x8 pf = acc_to_frag(s[kb], ss);
+#if DCV_ABL == 2  // ablation: no P.V MFMAs and no transposed V reads
+                asm volatile("" ::"v"(pf));
+#elif DCV_ABL == 3  // ablation: P.V MFMAs fed from registers (no transposed V reads)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(qf[ss + 2 * dt], pf, o[dt]);
+#else
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_cols_o(sKV, k, 0, kb, ss, dt), pf, o[dt]);
+#endif
             }
     };
     using No = std::integral_constant<bool, false>;

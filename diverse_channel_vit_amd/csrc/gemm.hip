@@ -139,134 +139,210 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
 }
 
 // gemm_nt geometry: 256 x 128 output tile, 8 waves as 4 (M) x 2 (N), each wave 64 x 64 = 2 x 2 MFMA 32x32x16 tiles.
-// Measured on MI355X: these short-K GEMMs (K = 384..1536) are bound by the rate at which a CU can pull operand bytes
-// through L2 into LDS (about 8 TB/s chip-wide with full 128-byte lines, half of that with 64-byte pieces), not by
-// MFMA issue: so (1) the tile is large (85 FLOP per operand byte vs 64 for 128 x 128), (2) every DMA instruction
-// fetches 8 rows x 128 contiguous bytes = whole cache lines (K is streamed in 64-wide stages), and (3) two of the three
-// 48 KB ring stages (96 KB per CU) are always in flight behind a counted vmcnt.
+// Measured on MI355X (tools/ab_bench.py ablations, M = 100 416, K = 384):
+//   * the main loop alone sustains ~965 TFLOP/s: operands arrive by LDS-DMA, whole 128-byte lines (8 rows x 128 B per
+//     instruction), K streamed in 64-wide stages through a 3-deep ring (two 48 KB stages always in flight);
+//   * the epilogue costs as much again (N = 1152: 92 us loop + 63 us epilogue; fc1 + GELU: 122 + 166 us) because a CU
+//     issues stores at only ~14 B/clk and, with one 144 KB workgroup per CU, nothing else runs meanwhile.
+// So the kernel is PERSISTENT: one workgroup per CU walks output tiles; after a tile's last stage it first issues the
+// auxiliary loads of its epilogue, then the NEXT tile's first two ring stages, and only then transposes / applies the
+// fused op / stores — from wave-private LDS slabs in the ring buffer that was consumed last, with no workgroup
+// barrier — so the store tail and the GELU arithmetic overlap the next tile's operand streaming.
+#ifndef DCV_GABL
+#define DCV_GABL 0  // timing-only ablations: 1 = no epilogue, 2 = no MFMA/LDS reads, 3 = no operand DMA
+#endif
 constexpr int NT_BM = 256, NT_BN = 128, NT_BK = 64, NT_STAGES = 3;
 constexpr int NT_A_BYTES = NT_BM * NT_BK * 2, NT_W_BYTES = NT_BN * NT_BK * 2, NT_STAGE_BYTES = NT_A_BYTES + NT_W_BYTES;  // 48 KB
+constexpr int NT_SMEM = NT_STAGES * NT_STAGE_BYTES;  // the ring (epilogue slabs alias the stage consumed last)
+
+// store instructions one wave issues in a full tile's epilogue (8 row-chunks of 8 columns per lane)
+template <int EPI>
+__device__ constexpr int nt_stores_per_wave() {
+    return (EPI == DCV_EPI_BIAS_GELU_BF16 || EPI == DCV_EPI_BIAS_RESID_F32) ? 16 : 8;
+}
+
+struct NtTile {
+    const bf16_t* gA[4];
+    const bf16_t* gW[2];
+    int m0, n0;
+};
+
+__device__ __forceinline__ void nt_tile_setup(const GemmNtArgs& a, int L, int tiles_n, int wave, int lane, NtTile& t) {
+    const int tm = L / tiles_n, tn = L - tm * tiles_n;
+    t.m0 = tm * NT_BM;
+    t.n0 = tn * NT_BN;
+    // one DMA instruction = 8 rows x 128 B (lane -> row lane>>3, physical chunk lane&7); the swizzle
+    // (physical chunk = logical ^ swz64(row)) is applied to the per-lane SOURCE chunk, the destination is linear.
+    // Wave w fills A rows [32w, 32w+32) (4 instructions) and W rows [16w, 16w+16) (2 instructions): 6 per stage.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 32 * wave + 8 * q + (lane >> 3);
+        t.gA[q] = a.A + (size_t)min(t.m0 + row, a.M - 1) * a.lda + (((lane & 7) ^ swz64(row)) * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = 16 * wave + 8 * q + (lane >> 3);
+        t.gW[q] = a.W + (size_t)min(t.n0 + row, a.N - 1) * a.ldw + (((lane & 7) ^ swz64(row)) * 8);
+    }
+}
+
+__device__ __forceinline__ void nt_issue(const NtTile& t, int kt, unsigned stage_base, unsigned dmaA, unsigned dmaW) {
+#if DCV_GABL != 3
+    glds16(t.gA[0] + kt * NT_BK, stage_base + dmaA);
+    glds16(t.gA[1] + kt * NT_BK, stage_base + dmaA + 1024);
+    glds16(t.gA[2] + kt * NT_BK, stage_base + dmaA + 2048);
+    glds16(t.gA[3] + kt * NT_BK, stage_base + dmaA + 3072);
+    glds16(t.gW[0] + kt * NT_BK, stage_base + dmaW);
+    glds16(t.gW[1] + kt * NT_BK, stage_base + dmaW + 1024);
+#endif
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
-    // ONE shared array (a second __shared__ object can make hipcc drain vmcnt before every ds_read): 144 KB
-    __shared__ __attribute__((aligned(16))) char smem[NT_STAGES * NT_STAGE_BYTES];
+    // ONE shared array (a second __shared__ object can make hipcc drain vmcnt before every ds_read)
+    __shared__ __attribute__((aligned(16))) char smem[NT_SMEM];
+    constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
+    constexpr bool HAS_AUX = (EPI == DCV_EPI_BIAS_RESID_F32) || (EPI == DCV_EPI_GELU_BWD_BF16) || (EPI == DCV_EPI_PATCH);
+    constexpr int S = nt_stores_per_wave<EPI>();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int h = lane >> 5, r32 = lane & 31;
     const int tiles_n = (a.N + NT_BN - 1) / NT_BN;
     const int tiles_m = (a.M + NT_BM - 1) / NT_BM;
-    const int lid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
-    const int m0 = tm * NT_BM, n0 = tn * NT_BN;
+    const int total = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    // tile walk: round k, workgroup w -> L = k*G + pos(w); pos gives every XCD (w & 7) a contiguous range of the
+    // round's tiles, so the N-tiles that share an A row-panel run on one XCD at the same time (speed only)
+    const int pos = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
 
-    // Stage image: [rows][64 k] bf16 = 128-byte rows of 8 chunks; physical chunk = logical ^ swz64(row) (conflict-free
-    // ds_read_b128).  One DMA instruction = 8 rows x 128 B = 1 KiB (lane -> row lane>>3, physical chunk lane&7): the
-    // destination is linear, the permutation is applied to the per-lane SOURCE chunk.
-    // Wave w fills A rows [32w, 32w+32) (4 instructions) and W rows [16w, 16w+16) (2 instructions): 6 per stage.
-    const bf16_t* gA[4];
-    const bf16_t* gW[2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = 32 * wave + 8 * q + (lane >> 3);
-        gA[q] = a.A + (size_t)min(m0 + row, a.M - 1) * a.lda + (((lane & 7) ^ swz64(row)) * 8);
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = 16 * wave + 8 * q + (lane >> 3);
-        gW[q] = a.W + (size_t)min(n0 + row, a.N - 1) * a.ldw + (((lane & 7) ^ swz64(row)) * 8);
-    }
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const unsigned dmaA = 32 * wave * 128, dmaW = NT_A_BYTES + 16 * wave * 128;  // wave-uniform byte offsets in a stage
     const int nk = a.K / NT_BK;
-
-#define NT_ISSUE(kt_)                                                                     \
-    {                                                                                     \
-        const unsigned sb_ = smem_base + ((kt_) % NT_STAGES) * NT_STAGE_BYTES;            \
-        glds16(gA[0] + (kt_) * NT_BK, sb_ + dmaA);                                        \
-        glds16(gA[1] + (kt_) * NT_BK, sb_ + dmaA + 1024);                                 \
-        glds16(gA[2] + (kt_) * NT_BK, sb_ + dmaA + 2048);                                 \
-        glds16(gA[3] + (kt_) * NT_BK, sb_ + dmaA + 3072);                                 \
-        glds16(gW[0] + (kt_) * NT_BK, sb_ + dmaW);                                        \
-        glds16(gW[1] + (kt_) * NT_BK, sb_ + dmaW + 1024);                                 \
-    }
-
-    NT_ISSUE(0)
-    if (nk > 1) NT_ISSUE(1)
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int sw = swz64(r32);
     const int rowA = (wm * 64 + r32) * 128, rowW = NT_A_BYTES + (wn * 64 + r32) * 128;
-
-    for (int kt = 0; kt < nk; ++kt) {
-        // my 6 DMAs of stage kt have landed once at most the next stage's 6 are outstanding
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone is done reading stage kt-1
-        if (kt + 2 < nk) NT_ISSUE(kt + 2)  // refills the buffer stage kt-1 used
-        const char* st = smem + (kt % NT_STAGES) * NT_STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int co = ((2 * ks + h) ^ sw) << 4;
-            bf16x8 af[2], wf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = as_bf16x8(lds_read128(st, rowA + i * 32 * 128 + co));
-                wf[i] = as_bf16x8(lds_read128(st, rowW + i * 32 * 128 + co));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
-        }
-    }
-#undef NT_ISSUE
-    __syncthreads();  // all stage reads done before the epilogue slabs overwrite the ring
-
-    // Epilogue: each wave transposes its 64x64 accumulator through a private, padded LDS slab (two 32-row halves)
-    // so that every lane owns 8 consecutive columns of a row: all global accesses are 16-byte and row-contiguous.
     constexpr int EP_LD = 68;  // floats per slab row (272 B: 16-byte aligned, rows shifted by 4 banks)
-    constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
-    constexpr bool HAS_AUX = (EPI == DCV_EPI_BIAS_RESID_F32) || (EPI == DCV_EPI_GELU_BWD_BF16) || (EPI == DCV_EPI_PATCH);
-    float* ep = reinterpret_cast<float*>(smem) + wave * 32 * EP_LD;      // 8.7 KB per wave, 69.6 KB in all
-    float* sbias = reinterpret_cast<float*>(smem + 8 * 32 * EP_LD * 4);  // 128 floats behind the slabs
-    if constexpr (HAS_BIAS) {
-        if (tid < NT_BN) sbias[tid] = a.bias[min(n0 + tid, a.N - 1)];
-    }
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
-    const int nn = n0 + wn * 64 + ecol;
-    const int nc = min(nn, a.N - 8);
+
+    int L = pos;
+    if (L >= total) return;
+    NtTile cur, nxt;
+    nt_tile_setup(a, L, tiles_n, wave, lane, cur);
+    int g = 0;  // global stage counter of this workgroup: stage g lives in ring buffer g % 3
+    nt_issue(cur, 0, smem_base + (g % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+    if (nk > 1) nt_issue(cur, 1, smem_base + ((g + 1) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+    bool stores_behind = false;  // the previous tile's S epilogue stores (exactly S) were issued after this tile's prefetch
+    // The lane's 8 bias values (its 8 output columns are fixed within a tile) live in registers and are loaded ONE TILE
+    // AHEAD, between the epilogue's auxiliary loads and the prefetch DMAs: hipcc's wait for that load then sits where
+    // nothing younger of ours is outstanding.  (A per-tile load at the loop top made hipcc emit vmcnt(0) there, which
+    // drained the previous tile's stores and the prefetch: fc2 + residual ran 40 % slower than without persistence.)
+    float bz[8], bz_next[8];
+    if constexpr (HAS_BIAS) {
+        load8_f32(a.bias + min(cur.n0 + wn * 64 + ecol, a.N - 8), bz);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(bz[e]));
+    }
+
+    for (;;) {
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ep[acc_row(r, h) * EP_LD + j * 32 + r32] = acc[i][j][r];
-        __syncthreads();
-        // 32 rows x 8 column chunks = 256 items = 4 passes; all auxiliary global loads are issued before any is used
-        float v[4][8], x[4][8], bz[8];
-        if constexpr (HAS_BIAS) load8_f32(sbias + wn * 64 + ecol, bz);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = q * 8 + erow;
-            const int mm = m0 + wm * 64 + i * 32 + row;
-            load8_f32(ep + row * EP_LD + ecol, v[q]);
-            if constexpr (HAS_AUX) epi_aux8<EPI>(a, min(mm, a.M - 1), nc, x[q]);
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            // Stage kt of this tile is complete once only YOUNGER operations of this wave are outstanding:
+            //   the 6 DMAs of stage kt+1 (issued one iteration / one tile earlier), and — for kt < 2 — the S stores of the
+            //   previous tile's epilogue, which were issued after this tile's first two stages.  vmcnt counts in issue order.
+            const bool dma_young = (kt + 1 < nk);
+            const bool st_young = stores_behind && (kt < 2);
+            if (st_young) {
+                if (dma_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S + 6) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
+            } else {
+                if (dma_young) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();  // everyone's stage g landed; everyone is done with buffer (g-1)%3 (reads and slabs)
+            if (kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+            const char* st = smem + (g % NT_STAGES) * NT_STAGE_BYTES;
+#if DCV_GABL != 2
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int co = ((2 * ks + h) ^ sw) << 4;
+                bf16x8 af[2], wf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = as_bf16x8(lds_read128(st, rowA + i * 32 * 128 + co));
+                    wf[i] = as_bf16x8(lds_read128(st, rowW + i * 32 * 128 + co));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
+            }
+#else
+            asm volatile("" ::"v"(st));
+#endif
         }
+        __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: its buffer (g-1)%3 now holds the slabs
+
+        // ---- epilogue of `cur`, overlapped with the first two stages of the next tile ----
+        const int Ln = L + G;
+        const bool has_next = Ln < total;
+        const int mbase = cur.m0 + wm * 64, nn = cur.n0 + wn * 64 + ecol;
+        const int nc = min(nn, a.N - 8);
+        float x[HAS_AUX ? 8 : 1][8];
+        if constexpr (HAS_AUX) {  // all auxiliary loads first: they are then OLDER than the prefetch DMAs below, so
+                                  // hipcc's own waits for them never wait for the prefetch
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int mm = m0 + wm * 64 + i * 32 + q * 8 + erow;
-            if (mm < a.M && nn < a.N) epi_store8<EPI>(a, mm, nn, v[q], x[q], bz);
+            for (int qq = 0; qq < 8; ++qq) epi_aux8<EPI>(a, min(mbase + qq * 8 + erow, a.M - 1), nc, x[qq]);
         }
-        __syncthreads();
+        if (has_next) {
+            nt_tile_setup(a, Ln, tiles_n, wave, lane, nxt);
+            if constexpr (HAS_BIAS) load8_f32(a.bias + min(nxt.n0 + wn * 64 + ecol, a.N - 8), bz_next);
+            nt_issue(nxt, 0, smem_base + (g % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+            if (nk > 1) nt_issue(nxt, 1, smem_base + ((g + 1) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+        }
+#if DCV_GABL == 1
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+        const bool full = false;
+#else
+        // wave-private slab (16 rows x 64 cols f32) in the buffer consumed last; LDS operations of one wave execute in
+        // order, so the write -> read -> next write sequence needs no barrier
+        float* ep = reinterpret_cast<float*>(smem + ((g + NT_STAGES - 1) % NT_STAGES) * NT_STAGE_BYTES) + wave * 16 * EP_LD;
+        const bool full = (cur.m0 + NT_BM <= a.M) && (cur.n0 + NT_BN <= a.N) && (EPI != DCV_EPI_PATCH);
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {  // quarter = 16 rows: block i = qt>>1, accumulator registers 8*(qt&1) .. +7
+            const int i = qt >> 1, rb = 8 * (qt & 1);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + r32] = acc[i][j][rb + r];
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) {  // 16 rows x 8 chunks = 128 items = 2 passes
+                const int row = ps * 8 + erow;
+                const int qq = qt * 2 + ps;
+                const int mm = mbase + qq * 8 + erow;
+                float v[8];
+                load8_f32(ep + row * EP_LD + ecol, v);
+                if (mm < a.M && nn < a.N) epi_store8<EPI>(a, mm, nn, v, x[HAS_AUX ? qq : 0], bz);
+            }
+        }
+#endif
+        if (!has_next) break;
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bz[e] = bz_next[e];
+        }
+        stores_behind = full;  // otherwise the store count is unknown: the next tile's first waits fall back to the stricter form
+        cur = nxt;
+        L = Ln;
     }
 }
 
@@ -417,7 +493,8 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
     GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n};
-    const int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
+    int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
+    if (grid > 256) grid = 256;  // persistent: one 144 KB workgroup per CU walks the tiles
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue) {
         case DCV_EPI_BIAS_BF16:

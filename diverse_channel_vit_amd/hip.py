@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcv_hip.so")
+LIB_PATH = os.environ.get("DCV_LIB", os.path.join(_HERE, "libdcv_hip.so"))  # DCV_LIB: A/B builds of the same ABI
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RESID_F32, EPI_PLAIN_BF16, EPI_GELU_BWD_BF16, EPI_PATCH = range(6)
 
