@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-entry time table of one step to stderr")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the HIP-graph-captured step (N=1 only)")
+    ap.add_argument("--force-dp", action="store_true", help="exercise the N>1 code path on one GPU: RCCL group of world size 1, collectives forced")
+    ap.add_argument("--hcs", action="store_true", help="secondary run (SURVEY §8d): enable_sample=True, hcs_sampling=lowest_cosine_prob, temp 1000 "
+                                                     "(variable sequence length, one host sync per step like the reference)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,24 +106,33 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
+        os.environ["NCCL_DEBUG"] = os.environ.get("DCV_NCCL_DEBUG", "WARN")  # no RCCL version banner on stdout: ONE JSON line
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29655"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import diverse_channel_vit_amd as dcv
     from diverse_channel_vit_amd import hip
     hip.load()
 
     cfg = model_cfg(args.arch, args.channels, args.img, 16, args.classes)
+    if args.hcs:
+        cfg.update(enable_sample=True, hcs_sampling="lowest_cosine_prob", hcs_sampling_temp=1000.0)
+        import random
+        random.seed(33978 + 21022023)  # same seed on every rank (dataset_utils.py:589): ranks draw the same subset
+        torch.manual_seed(33978 + 21022023)
     torch.manual_seed(0)
     model = dcv.dichavit(cfg, mapper={"train": list(range(args.channels))}).to(dev)
     model.train()
     model._ensure_arena(dev)
     dp = None
-    if world > 1:
-        dp = dcv.DataParallel(model)
+    if use_dp:
+        dp = dcv.DataParallel(model, force_collectives=args.force_dp)
         dp.broadcast_parameters(0)
         dp.hook_misc_params()
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (world == 1) and not args.no_graph and not use_dp and not args.hcs
     opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=4.9e-5, betas=(0.9, 0.999), eps=1e-8,
                        weight_decay=0.04, model=model, capturable=use_graph)
     rs = np.random.RandomState(1234 + rank)
@@ -143,7 +155,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +191,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     rec = prof[dominant] if use_graph else hip.set_profiler(None)[dominant]
-    if world > 1:
+    if use_dp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -222,13 +234,16 @@ def main():
                        "global_batch": args.batch * world, "seq_len": N, "parallelism": f"dp{world}",
                        "step_roofline_frac": round(imgs / world * TRAIN_GFLOP_PER_IMG * 1e9 / PEAK_BF16, 4) if (args.arch, C, args.img) == ("small", 8, 224) else None,
                        "final_loss": round(final_loss, 5), "host_syncs_per_step": 0,
-                       "launch": "hip-graph replay of the captured step" if use_graph else "eager"},
+                       "launch": "hip-graph replay of the captured step" if use_graph else "eager",
+                       **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)",
+                           "dp_buckets_per_step": None} if args.hcs else {}),
+                       **({"dp_buckets_launched": dp.buckets_launched} if dp is not None else {})},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.channels, args.img, args.classes)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
 

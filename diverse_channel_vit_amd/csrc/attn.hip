@@ -111,10 +111,18 @@ __device__ __forceinline__ bf16x8 frag_cols_o(const char* base, const LaneOffs& 
 #ifndef DCV_ABL
 #define DCV_ABL 0
 #endif
+#ifndef DCV_ABL2
+#define DCV_ABL2 0
+#endif
 #ifndef DCV_KV_STAGES
 #define DCV_KV_STAGES 4
 #endif
+#ifndef DCV_FWD_WAVES
+#define DCV_FWD_WAVES 4
+#endif
 constexpr int KV_STAGES = DCV_KV_STAGES, KV_STAGE_BYTES = 16384;
+constexpr int FWD_WAVES = DCV_FWD_WAVES, FWD_QTILE = 32 * FWD_WAVES;  // query rows per workgroup: K/V re-reads scale with 1/FWD_QTILE
+constexpr int KV_DMA_PER_WAVE = 16 / FWD_WAVES;  // DMA instructions per stage per wave (8 rows x 128 B each; K: 8, V: 8)
 
 struct KvDma {
     const bf16_t* kbase;  // K rows of this (batch, head)
@@ -127,7 +135,7 @@ struct KvDma {
 __device__ __forceinline__ void kv_issue(const KvDma& d, int t) {
     const unsigned sb = d.smem_base + (t % KV_STAGES) * KV_STAGE_BYTES + d.wave_off;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < KV_DMA_PER_WAVE / 2; ++j) {  // 4 waves: rows [16w,16w+16) in two 8-row pieces; 8 waves: rows [8w,8w+8)
         const int row = min(t * 64 + d.rowl + 8 * j, d.N - 1);  // keys >= N: clamp (masked by the caller)
         const size_t off = (size_t)row * d.rs + d.lc8[j];
         glds16(d.kbase + off, sb + j * 1024);
@@ -135,11 +143,11 @@ __device__ __forceinline__ void kv_issue(const KvDma& d, int t) {
     }
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char sKV[KV_STAGES * KV_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nqt = (a.N + 127) / 128;
+    const int nqt = (a.N + FWD_QTILE - 1) / FWD_QTILE;
     const int BH = a.B * a.H;
     int bh, qt;
     if ((BH & 7) == 0) {  // keep all query tiles of one (batch, head) on one XCD: K/V stay in that L2
@@ -161,15 +169,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     dma.vbase = Qb + 2 * D;
     dma.rs = rs;
     dma.N = a.N;
-    dma.rowl = 16 * wave + (lane >> 3);
+    dma.rowl = (64 / FWD_WAVES) * wave + (lane >> 3);
     dma.lc8[0] = ((lane & 7) ^ swz64(dma.rowl)) * 8;
     dma.lc8[1] = ((lane & 7) ^ swz64(dma.rowl + 8)) * 8;
     dma.smem_base = __builtin_amdgcn_readfirstlane(lds_addr(sKV));
-    dma.wave_off = 16 * wave * 128;
+    dma.wave_off = (64 / FWD_WAVES) * wave * 128;
     for (int st = 0; st < KV_STAGES - 1; ++st)
         if (st < nt) kv_issue(dma, st);
 
-    const int q = qt * 128 + wave * 32 + r32;  // this lane's query row
+    const int q = qt * FWD_QTILE + wave * 32 + r32;  // this lane's query row
     const int qc = min(q, a.N - 1);
     bf16x8 qf[4];
 #pragma unroll
@@ -190,11 +198,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     auto tile = [&](auto MASKED, int t) {
         // my 4 DMAs of stage t have landed once at most the younger stages' are outstanding
         const int rem = nt - 1 - t;
-        if (KV_STAGES >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#if !(DCV_ABL2 & 1)
+        if (KV_STAGES >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KV_DMA_PER_WAVE) : "memory");
+        else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone's stage t landed; everyone is done reading stage t-1
+#endif
+#if !(DCV_ABL2 & 2)
         if (t + KV_STAGES - 1 < nt) kv_issue(dma, t + KV_STAGES - 1);
+#endif
         LaneOffs k = lo;  // this stage's addresses: 8 integer adds per tile, the rest are immediates
         const int so = (t % KV_STAGES) * KV_STAGE_BYTES;
 #pragma unroll
@@ -209,7 +221,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int kb = 0; kb < 2; ++kb) {
             zero_acc(s[kb]);
 #pragma unroll
+#if DCV_ABL2 & 4
+            for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(qf[(ks + kb) & 3], qf[ks], s[kb]);
+#else
             for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows_o(sKV, k, 0, kb, ks), qf[ks], s[kb]);
+#endif
         }
         if constexpr (decltype(MASKED)::value) {  // keys >= N do not exist
 #pragma unroll
@@ -551,8 +567,8 @@ extern "C" int dcv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, 
     if (rc) return rc;
     if (!o || !lse) return DCV_ERR_NULL;
     AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, nullptr, lse, nullptr, nullptr, B, N, H, scale};
-    const int grid = B * H * ((N + 127) / 128);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    const int grid = B * H * ((N + FWD_QTILE - 1) / FWD_QTILE);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

@@ -148,6 +148,9 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
 // auxiliary loads of its epilogue, then the NEXT tile's first two ring stages, and only then transposes / applies the
 // fused op / stores — from wave-private LDS slabs in the ring buffer that was consumed last, with no workgroup
 // barrier — so the store tail and the GELU arithmetic overlap the next tile's operand streaming.
+#ifndef DCV_TABL
+#define DCV_TABL 0  // gemm_tn timing-only ablations: 1 = no atomic epilogue, 2 = no MFMA / transposed reads
+#endif
 #ifndef DCV_GABL
 #define DCV_GABL 0  // timing-only ablations: 1 = no epilogue, 2 = no MFMA/LDS reads, 3 = no operand DMA
 #endif
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
         if (kt + 1 < nk) { TN_LOAD_TILE(kt + 1) }
         const char* sY = smem[cur][0];
         const char* sX = smem[cur][1];
+#if DCV_TABL != 2
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int row0 = 16 * ks + trow;
@@ -450,10 +454,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
+#else
+        asm volatile("" ::"v"(sY), "v"(sX));
+#endif
         if (kt + 1 < nk) { TN_STORE_TILE(cur ^ 1) }
         __syncthreads();
     }
 
+#if DCV_TABL == 1
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (a.M > 0) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

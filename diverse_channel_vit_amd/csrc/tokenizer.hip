@@ -246,7 +246,32 @@ __global__ __launch_bounds__(256) void ortho_bwd_kernel(const float* __restrict_
     }
 }
 
+// token gather / scatter for dropout_tokens_hcs (dichavit.py:568-627): out[b,k,:] = x[b,idx[k],:] and its adjoint
+__global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restrict__ x, const int* __restrict__ idx,
+                                                            float* __restrict__ out, int B, int N, int Nk, int D4, int scatter) {
+    const size_t total = (size_t)B * Nk * D4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int d = i % D4;
+        const size_t r = i / D4;
+        const int k = r % Nk, b = r / Nk;
+        const size_t full = ((size_t)b * N + idx[k]) * D4 + d, kept = ((size_t)b * Nk + k) * D4 + d;
+        if (scatter) reinterpret_cast<float4*>(out)[full] = reinterpret_cast<const float4*>(x)[kept];
+        else reinterpret_cast<float4*>(out)[kept] = reinterpret_cast<const float4*>(x)[full];
+    }
+}
+
 }  // namespace
+
+extern "C" int dcv_gather_tokens(const float* x, const int* idx, float* out, int B, int N, int Nk, int D, int scatter, void* stream) {
+    if (!x || !idx || !out) return DCV_ERR_NULL;
+    if (B <= 0 || N <= 0 || Nk <= 0 || Nk > N || D <= 0 || (D & 3)) return DCV_ERR_SHAPE;
+    size_t total = (size_t)B * Nk * (D / 4);
+    size_t grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(gather_tokens_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, idx, out, B, N, Nk, D / 4, scatter);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
 
 extern "C" int dcv_im2col_bf16(const float* x, const int* ch_idx, void* out, int B, int Ct, int C, int H, int W, int P, void* stream) {
     if (!x || !ch_idx || !out) return DCV_ERR_NULL;

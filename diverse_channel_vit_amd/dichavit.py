@@ -163,8 +163,8 @@ class ChannelVisionTransformer(_Holder):
             if cfg.block_type == "block_v2":
                 raise ValueError("block_type=block_v2 is experimental in the reference (SURVEY §2.1 #2) and not provided")
             raise ValueError(f"Unknown block type: {cfg.block_type}")
-        if _cfg_get(cfg, "dropout_tokens_hcs", "none") not in (None, "none"):
-            raise ValueError("dropout_tokens_hcs variants (dichavit.py:568-627) are not provided by the HIP path yet")
+        if _cfg_get(cfg, "dropout_tokens_hcs", "none") not in (None, "none", "random", "channel", "channel_random50", "token_random50"):
+            raise ValueError(f"Unknown dropout_tokens_hcs: {cfg.dropout_tokens_hcs}")
         if (_cfg_get(cfg, "drop_path_rate", 0.0) or 0.0) != 0.0:
             raise ValueError("drop_path_rate > 0 is not supported by the HIP path (all reference scripts use 0)")
         self.num_features = self.embed_dim = self.out_dim = embed_dim
@@ -203,8 +203,8 @@ class _EncoderFn(torch.autograd.Function):
        outputs: CLS feature after the final LayerNorm [B,D] f32, ortho statistics [B,2] f32."""
 
     @staticmethod
-    def forward(ctx, model, ch_idx_dev, C, want_ortho, x, E, pos_tab, *params):
-        st = model._run_forward(x, ch_idx_dev, C, E, pos_tab, want_ortho, save=any(ctx.needs_input_grad))
+    def forward(ctx, model, ch_idx_dev, C, want_ortho, keep, x, E, pos_tab, *params):
+        st = model._run_forward(x, ch_idx_dev, C, E, pos_tab, want_ortho, save=any(ctx.needs_input_grad), keep=keep)
         ctx.model = model
         ctx.st = st
         return st["feat"], st["stats"]
@@ -218,7 +218,7 @@ class _EncoderFn(torch.autograd.Function):
         dE, dpos, grads = model._run_backward(st, dfeat.contiguous(), dstats)
         st["consumed"] = True
         st.clear()
-        return (None, None, None, None, None, dE, dpos) + tuple(grads)
+        return (None, None, None, None, None, None, dE, dpos) + tuple(grads)
 
 
 class DiChaViT(nn.Module):
@@ -387,6 +387,28 @@ class DiChaViT(nn.Module):
                 pe.counter[k] += v
         return picked, idx
 
+    def _token_keep(self, nc, n):
+        """dropout_tokens_hcs (dichavit.py:568-627): positions (CLS = 0 always first) of the tokens that stay, or None.
+        Same python-RNG draw order and the same off-by-CLS bookkeeping as the reference (cinHW = 1 + nc*n)."""
+        mode = _cfg_get(self.cfg, "dropout_tokens_hcs", "none")
+        if mode in (None, "none") or not self.training:
+            return None
+        cinHW = 1 + nc * n
+        HW = cinHW // nc
+        if HW != n:
+            raise ValueError("dropout_tokens_hcs with a single channel is ill-defined in the reference (mask length mismatch)")
+        if mode in ("random", "token_random50"):
+            k = (random.randint(1, nc) if mode == "random" else int(math.ceil(0.5 * nc))) * HW
+            chosen = set(random.sample(range(cinHW), k=k))
+            return [0] + [i for i in range(1, cinHW) if i in chosen]
+        k = random.randint(1, nc) if mode == "channel" else int(math.ceil(0.5 * nc))
+        chans = set(random.sample(range(nc), k=k))
+        keep = [0]
+        for c in range(nc):
+            if c in chans:
+                keep.extend(range(1 + c * HW, 1 + (c + 1) * HW))
+        return keep
+
     def _eval_channel_embed(self, chunk_name, training_chunks, new_channel_init):
         """Leave-one-out channel embeddings at eval time (dichavit.py:219-374; static variants)."""
         pe = self.feature_extractor.patch_embed
@@ -443,7 +465,7 @@ class DiChaViT(nn.Module):
     # ---------------------------------------------------------------------------------------
     # forward / backward drivers (kernel sequences)
     # ---------------------------------------------------------------------------------------
-    def _run_forward(self, x, ch_idx_dev, C, E, pos_tab, want_ortho, save):
+    def _run_forward(self, x, ch_idx_dev, C, E, pos_tab, want_ortho, save, keep=None):
         fe = self.feature_extractor
         D, H = self.dim, fe.num_heads
         P = fe.patch_size
@@ -476,6 +498,15 @@ class DiChaViT(nn.Module):
                 st.update(Y=Y, S=S, tot=tot, inv=inv)
         if save:
             st["Xp"] = Xp
+        if keep is not None:  # dropout_tokens_hcs: the encoder sees only the kept token rows (CLS first)
+            keep_dev = self._index_tensor(keep, torch.int32, dev)
+            Nk = len(keep)
+            xk = torch.empty(B, Nk, D, dtype=f32, device=dev)
+            hip.gather_tokens(xs, keep_dev, xk, B, N, Nk, D)
+            st.update(keep_dev=keep_dev, N_full=N)
+            xs, N = xk, Nk
+            M = B * N
+            st.update(N=N, M=M)
         # --- encoder blocks ---
         scale = 64 ** -0.5
         layers = []
@@ -561,6 +592,11 @@ class DiChaViT(nn.Module):
             if dp is not None:
                 dp.grad_ready(ga, *self._range_of([blk.norm1.weight, blk.mlp.fc2.bias]))
         # --- tokeniser ---
+        if st.get("keep_dev") is not None:  # adjoint of the token gather: dropped tokens receive no gradient
+            Nf = st["N_full"]
+            dxf = torch.zeros(B * Nf, D, dtype=f32, device=dev)
+            hip.gather_tokens(dx, st["keep_dev"], dxf, B, Nf, N, D, scatter=True)
+            dx = dxf
         pe = fe.patch_embed
         dYl = None
         if st["want_ortho"] and dstats is not None:
@@ -618,7 +654,8 @@ class DiChaViT(nn.Module):
         want_ortho = bool(self.training and lam_o > 0)
         pos_tab = self._pos_table(C, n, Hi, Wi)
         ch_idx_dev = self._index_tensor(idx, torch.int32, x.device)
-        feat, stats = _EncoderFn.apply(self, ch_idx_dev, C, want_ortho, x, channel_embed, pos_tab, *self._enc_params)
+        keep = self._token_keep(C, n)
+        feat, stats = _EncoderFn.apply(self, ch_idx_dev, C, want_ortho, keep, x, channel_embed, pos_tab, *self._enc_params)
         # --- regularisers (tiny tensors; models/loss_fn.py) ---
         extra = 0
         if want_ortho:

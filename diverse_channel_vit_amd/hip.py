@@ -29,6 +29,7 @@ _SIGS = {
     "dcv_attn_bwd_dkdv": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_im2col_bf16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "dcv_patch_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "dcv_gather_tokens": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "dcv_fill_cls": ([_vp, _vp, _vp, _i, _l, _i, _vp], _i),
     "dcv_ortho_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_ortho_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
@@ -175,6 +176,10 @@ def im2col(x, ch_idx, out, B, Ct, C, H, W, P):
 
 def patch_bwd(dx0, dYloss, dY_bf16, dE, dpos, dcls, B, C, n, D):
     _check(load().dcv_patch_bwd(_p(dx0), _p(dYloss), _p(dY_bf16), _p(dE), _p(dpos), _p(dcls), B, C, n, D, _stream()), "dcv_patch_bwd")
+
+
+def gather_tokens(x, idx, out, B, N, Nk, D, scatter=False):
+    _check(load().dcv_gather_tokens(_p(x), _p(idx), _p(out), B, N, Nk, D, 1 if scatter else 0, _stream()), "dcv_gather_tokens")
 
 
 def fill_cls(x, cls, pos0, B, batch_stride, D):

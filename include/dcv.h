@@ -75,6 +75,9 @@ int dcv_im2col_bf16(const float* x, const int* ch_idx, void* out, int B, int Ct,
 /* one pass over d(tokens) f32 [B,1+C*n,D]: dY_bf16 [B*C*n,D] = dx0[:,1:] (+ dYloss) ; dE [C,D], dpos [1+n,D], dcls [D] += */
 int dcv_patch_bwd(const float* dx0, const float* dYloss, void* dY_bf16, float* dE, float* dpos, float* dcls, int B, int C, int n,
                   int D, void* stream);
+/* dropout_tokens_hcs (dichavit.py:568-627): scatter == 0: out[b,k,:] = x[b,idx[k],:] (x [B,N,D] -> out [B,Nk,D]);
+ * scatter != 0: out[b,idx[k],:] = x[b,k,:] (x [B,Nk,D] -> out [B,N,D], caller zero-fills out first).  f32, D % 4 == 0. */
+int dcv_gather_tokens(const float* x, const int* idx, float* out, int B, int N, int Nk, int D, int scatter, void* stream);
 int dcv_fill_cls(float* x, const float* cls, const float* pos0, int B, long batch_stride, int D, void* stream);
 
 /* ortho_proj_loss_fn_v2 statistics (loss_fn.py:24-48): stats[b] = (pos_sum, neg_sum) of image b.

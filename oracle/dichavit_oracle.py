@@ -269,19 +269,42 @@ def encode(sd: Dict[str, Tensor], z: Tensor, cfg) -> Tensor:
     return f[:, 0]  # dichavit.py:651-652
 
 
+def token_keep(mode: Optional[str], nc: int, n: int, rng: _pyrandom.Random) -> Optional[List[int]]:
+    """dropout_tokens_hcs (models/dichavit.py:568-627): token positions kept (CLS = 0 first), training only.
+    cinHW counts the CLS token (x.shape[1]), exactly as the reference does."""
+    if mode in (None, "none"):
+        return None
+    cinHW = 1 + nc * n
+    HW = cinHW // nc
+    if mode in ("random", "token_random50"):
+        k = (rng.randint(1, nc) if mode == "random" else int(math.ceil(0.5 * nc))) * HW  # :571 / :617
+        chosen = set(rng.sample(range(cinHW), k=k))  # :572 / :618
+        return [0] + [i for i in range(1, cinHW) if i in chosen]  # :574-579
+    k = rng.randint(1, nc) if mode == "channel" else int(math.ceil(0.5 * nc))  # :585 / :602
+    chans = set(rng.sample(range(nc), k=k))  # :587 / :604
+    keep = [0]
+    for c in range(nc):
+        if c in chans:
+            keep.extend(range(1 + c * HW, 1 + (c + 1) * HW))
+    return keep
+
+
 def forward(sd: Dict[str, Tensor], x: Tensor, cfg, ch_ids: Sequence[int], idx: Sequence[int],
-            channel_embed_rows: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-    """DiChaViT.forward (models/dichavit.py:844-861).  Returns (logits-or-features, extra)."""
+            channel_embed_rows: Optional[Tensor] = None, keep: Optional[Sequence[int]] = None) -> Tuple[Tensor, Tensor]:
+    """DiChaViT.forward (models/dichavit.py:844-861).  Returns (logits-or-features, extra).
+    keep: token positions that survive dropout_tokens_hcs (from token_keep)."""
     z, extra = tokenise(sd, x, cfg, ch_ids, idx, channel_embed_rows)
+    if keep is not None:
+        z = z[:, list(keep)]
     f = encode(sd, z, cfg)
     if "classifer_head.weight" in sd:  # absent for CHAMMI (dichavit.py:797-801)
         f = f @ sd["classifer_head.weight"].t() + sd["classifer_head.bias"]
     return f, extra
 
 
-def train_loss(sd, x, y, cfg, ch_ids, idx, extra_loss_lambda: float = 1.0):
+def train_loss(sd, x, y, cfg, ch_ids, idx, extra_loss_lambda: float = 1.0, keep=None):
     """train_one_batch_regular's loss (trainer.py:986-995)."""
-    logits, extra = forward(sd, x, cfg, ch_ids, idx)
+    logits, extra = forward(sd, x, cfg, ch_ids, idx, keep=keep)
     main = F.cross_entropy(logits, y)
     return main + extra_loss_lambda * extra, main, extra, logits
 

@@ -255,6 +255,55 @@ def case_eval(dichavit, loss_fn):
     save("eval_newch", dict(cfg=cfg, mapper=mapper, n_channels=7, img=32, num_classes=9, B=3, seed=61), arrays)
 
 
+def case_resolution(dichavit, loss_fn):
+    """Input resolution different from the model's img_size: the positional grid is really resampled
+    (4x4 -> 6x6 and 4x4 -> 3x3; dichavit.py:536-546) and — in training — its gradient takes the true bicubic adjoint
+    (output size != input size, so ATen's same-size early-out does not apply)."""
+    cfg = base_cfg(patch_size=8)
+    mapper = {"train": [0, 1, 2, 3]}
+    arrays = {}
+    for img_in in (48, 24):
+        model, keys = build(dichavit, cfg, mapper, 4, 32, 6, 95)
+        model.train()
+        x, y = orc.make_batch(96 + img_in, 2, 4, img_in, 6)
+        out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+        loss.backward()
+        arrays[f"logits_{img_in}"] = out.detach().numpy()
+        arrays[f"loss_{img_in}"] = np.array(loss.item())
+        arrays[f"gpos_{img_in}"] = model.feature_extractor.pos_embed.grad.numpy().copy()
+        arrays[f"gnorm_proj_{img_in}"] = np.array(model.feature_extractor.patch_embed.proj.weight.grad.norm().item())
+        model.eval()
+        with torch.inference_mode():
+            arrays[f"eval_{img_in}"] = model(x, "train", None, new_channel_init=None).numpy()
+        print(f"  resolution {img_in}: loss={loss.item():.6f}")
+    save("resolution", dict(cfg=cfg, mapper=mapper, n_channels=4, img=32, num_classes=6, B=2, seed=95), arrays)
+
+
+def case_tokendrop(dichavit, loss_fn):
+    """dropout_tokens_hcs variants (dichavit.py:568-627) with the python RNG seeded."""
+    mapper = {"train": [0, 1, 2, 3, 4]}
+    arrays, meta = {}, dict(mapper=mapper, n_channels=5, img=32, num_classes=6, B=2, seed=97, draws=[])
+    x, y = orc.make_batch(98, 2, 5, 32, 6)
+    for k, (mode, pyseed) in enumerate([("random", 1), ("channel", 2), ("channel_random50", 3), ("token_random50", 4), ("channel", 7)]):
+        cfg = base_cfg(patch_size=8, dropout_tokens_hcs=mode)
+        meta["cfg"] = base_cfg(patch_size=8)
+        model, keys = build(dichavit, cfg, mapper, 5, 32, 6, 97)
+        model.train()
+        random.seed(pyseed)
+        out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+        loss.backward()
+        arrays[f"d{k}_logits"] = out.detach().numpy()
+        arrays[f"d{k}_loss"] = np.array(loss.item())
+        arrays[f"d{k}_gnorm_proj"] = np.array(model.feature_extractor.patch_embed.proj.weight.grad.norm().item())
+        arrays[f"d{k}_gpos"] = model.feature_extractor.pos_embed.grad.numpy().copy()
+        keep = orc.token_keep(mode, 5, 16, random.Random(pyseed))
+        meta["draws"].append(dict(mode=mode, pyseed=pyseed, n_keep=len(keep)))
+        print(f"  tokendrop {mode}: keep {len(keep)} of 81, loss={loss.item():.6f}")
+    save("tokendrop", meta, arrays)
+
+
 def _curve(dichavit, name, cfg, n_channels, img, K, B, seed, steps, n_batches, lr=4.9e-5, wd=0.04):
     """`steps` training steps of trainer.train_one_batch_regular's body (trainer.py:963-1006):
     zero_grad, forward, CE + extra, backward, AdamW step.  torch.optim.AdamW stands in for timm's
@@ -305,7 +354,7 @@ def case_schedules(dichavit, loss_fn):
     save("schedules", meta, arrays)
 
 
-CASES = dict(schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
+CASES = dict(tokendrop=case_tokendrop, resolution=case_resolution, schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
              chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp)
 
 if __name__ == "__main__":

@@ -361,3 +361,51 @@ def test_base_width_train_step(gpu_device):
     assert abs(loss.item() - loss_ref) <= 2e-2
     worst = check_grads(model, sd_ref)
     print(f"base width: loss {loss.item():.6f} (oracle {loss_ref:.6f}) worst grad rel err {worst}")
+
+
+def test_resolution_change_parity(gpu_device):
+    """Images of another resolution than the model's img_size (48 and 24 px on a 32-px model): the positional grid
+    is resampled 4x4 -> 6x6 / 3x3 and its gradient is the exact bicubic adjoint (golden from the reference)."""
+    meta, a = load_golden("resolution")
+    for img_in in (48, 24):
+        model, _ = build(meta, gpu_device)
+        x, y = orc.make_batch(96 + img_in, 2, 4, img_in, 6)
+        out, extra = model(x.to(gpu_device), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = torch.nn.functional.cross_entropy(out, y.to(gpu_device)) + extra
+        loss.backward()
+        ref = a[f"logits_{img_in}"]
+        assert np.abs(out.detach().cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max()
+        assert abs(loss.item() - float(a[f"loss_{img_in}"])) <= 5e-3
+        g = model.feature_extractor.pos_embed.grad.cpu().numpy()
+        gr = a[f"gpos_{img_in}"]
+        assert np.linalg.norm(g - gr) <= 5e-2 * np.linalg.norm(gr), (img_in, np.linalg.norm(g - gr), np.linalg.norm(gr))
+        model.eval()
+        with torch.inference_mode():
+            ev = model(x.to(gpu_device), "train", None, new_channel_init=None)
+        assert np.abs(ev.cpu().numpy() - a[f"eval_{img_in}"]).max() <= 3e-2 * np.abs(a[f"eval_{img_in}"]).max()
+
+
+def test_token_drop_parity(gpu_device):
+    """dropout_tokens_hcs (dichavit.py:568-627): the HIP path draws the same token subset as the reference from the
+    seeded python RNG, runs the encoder on the kept rows only, and scatters the gradient back."""
+    meta, a = load_golden("tokendrop")
+    x, y = orc.make_batch(98, 2, 5, 32, 6)
+    for k, d in enumerate(meta["draws"]):
+        m2 = dict(meta, cfg=dict(meta["cfg"], dropout_tokens_hcs=d["mode"]))
+        model, _ = build(m2, gpu_device)
+        random.seed(d["pyseed"])
+        out, extra = model(x.to(gpu_device), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = torch.nn.functional.cross_entropy(out, y.to(gpu_device)) + extra
+        loss.backward()
+        ref = a[f"d{k}_logits"]
+        assert np.abs(out.detach().cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max(), d
+        assert abs(loss.item() - float(a[f"d{k}_loss"])) <= 5e-3
+        g = model.feature_extractor.pos_embed.grad.cpu().numpy()
+        gr = a[f"d{k}_gpos"]
+        assert np.linalg.norm(g - gr) <= 5e-2 * np.linalg.norm(gr), d
+        gp = model.feature_extractor.patch_embed.proj.weight.grad.norm().item()
+        assert abs(gp - float(a[f"d{k}_gnorm_proj"])) <= 5e-2 * gp
+        # eval ignores the option
+        model.eval()
+        with torch.inference_mode():
+            assert model(x.to(gpu_device), "train", None).shape == (2, 6)

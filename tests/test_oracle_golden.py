@@ -190,3 +190,34 @@ def test_curve_so2sat_golden():
             for k in names:
                 orc.adamw_step(sd[k], sd[k].grad, m[k], v[k], s + 1, meta["lr"], 0.9, 0.999, meta["eps"], meta["wd"])
         assert abs(loss.item() - a["losses"][s, 0]) < 2e-4, (s, loss.item(), a["losses"][s, 0])
+
+
+def test_resolution_change_goldens():
+    """Other input resolution than img_size: real grid resample forward and the exact adjoint backward."""
+    meta, a = load_golden("resolution")
+    for img_in in (48, 24):
+        sd = _state(meta)
+        x, y = orc.make_batch(96 + img_in, 2, 4, img_in, 6, dtype=torch.float64)
+        loss, main, extra, logits = orc.train_loss(sd, x, y, meta["cfg"], [0, 1, 2, 3], [0, 1, 2, 3])
+        loss.backward()
+        assert np.abs(logits.detach().numpy() - a[f"logits_{img_in}"]).max() < 2e-5
+        assert abs(loss.item() - float(a[f"loss_{img_in}"])) < 5e-6
+        g = sd["feature_extractor.pos_embed"].grad.numpy()
+        ref = a[f"gpos_{img_in}"]
+        assert np.abs(g - ref).max() < 2e-4 * np.abs(ref).max(), img_in
+
+
+def test_token_drop_goldens():
+    """dropout_tokens_hcs variants: same python-RNG draws as the reference, same logits / loss / gradients."""
+    meta, a = load_golden("tokendrop")
+    x, y = orc.make_batch(98, 2, 5, 32, 6, dtype=torch.float64)
+    for k, d in enumerate(meta["draws"]):
+        sd = _state(meta)
+        keep = orc.token_keep(d["mode"], 5, 16, random.Random(d["pyseed"]))
+        assert len(keep) == d["n_keep"] and keep[0] == 0
+        loss, main, extra, logits = orc.train_loss(sd, x, y, meta["cfg"], [0, 1, 2, 3, 4], [0, 1, 2, 3, 4], keep=keep)
+        loss.backward()
+        assert np.abs(logits.detach().numpy() - a[f"d{k}_logits"]).max() < 2e-5, d
+        assert abs(loss.item() - float(a[f"d{k}_loss"])) < 5e-6
+        g = sd["feature_extractor.pos_embed"].grad.numpy()
+        assert np.abs(g - a[f"d{k}_gpos"]).max() < 2e-4 * np.abs(a[f"d{k}_gpos"]).max()
