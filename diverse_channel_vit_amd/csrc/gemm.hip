@@ -12,6 +12,7 @@
 // Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles.
 // Register-staged double-buffered LDS (global loads for tile t+1 are issued before the MFMAs of
 // tile t and written to LDS after them: one barrier per K-tile).
+#include <stdlib.h>
 #include "dcv_common.hpp"
 #include "../../include/dcv.h"
 
@@ -498,6 +499,171 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_tn384: the same weight-gradient product with a 384 (P) x 128 (Q) output tile per workgroup: 96 FLOP per operand
+// byte pulled through L2 -> LDS instead of 64 (the 128 x 128 kernel's loop is load-bound: 129 of 157 us with its MFMAs
+// removed).  8 waves as 4 (P) x 2 (Q), each wave 96 x 64 = 3 x 2 MFMA tiles.  The reduction (token rows) streams in 32-row
+// stages through a 4-deep LDS-DMA ring; a stage is four [32 rows][128 cols] images (Y columns 0-127 / 128-255 / 256-383,
+// X columns 0-127), each 256-byte row swizzled per 64-byte segment (segment ^= row & 3) so that ds_read_b64_tr_b16 is
+// conflict-free; every DMA instruction moves 4 rows x 256 contiguous bytes.  Used when P % 384 == 0 and Q % 128 == 0
+// (all DiChaViT-S/B shapes); otherwise gemm_tn_kernel.
+constexpr int T3_BK = 32, T3_STAGES = 4, T3_IMG = T3_BK * 256, T3_STAGE_BYTES = 4 * T3_IMG;  // 8 KB images, 32 KB stages
+
+__global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[T3_STAGES * T3_STAGE_BYTES];  // 128 KB: one workgroup per CU
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wq = wave & 1;
+    const int h = lane >> 5, r32 = lane & 31, li = lane & 15, g1 = (lane >> 4) & 1;
+    const int tiles_q = a.Q / 128, tiles = tiles_q * (a.P / 384);
+    int bid = xcd_remap(blockIdx.x, tiles * a.splits);
+    const int split = bid / tiles;
+    bid -= split * tiles;
+    const int tq = bid % tiles_q, tp = bid / tiles_q;
+    const int p0 = tp * 384, q0 = tq * 128;
+    const int m_begin = split * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    if (m_begin >= m_end) return;
+    const int nk = (m_end - m_begin + T3_BK - 1) / T3_BK;
+    const int last_valid = (m_end - m_begin) - (nk - 1) * T3_BK;  // rows of the last stage that exist (1..32)
+
+    // DMA: wave w fills image w>>1, rows [16*(w&1), +16) in four 4-row pieces; lane -> row lane>>4, physical chunk lane&15
+    const int img = wave >> 1;
+    const bf16_t* gsrc = (img < 3) ? a.Y + p0 + 128 * img : a.X + q0;
+    const int ld = (img < 3) ? a.ldy : a.ldx;
+    const int prow0 = 16 * (wave & 1) + (lane >> 4);  // + 4*j
+    int lc8[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = prow0 + 4 * j, pc = lane & 15;
+        lc8[j] = (((((pc >> 2) ^ (row & 3)) << 2) | (pc & 3))) * 8;  // logical chunk for this physical slot
+    }
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned dma_off = img * T3_IMG + 16 * (wave & 1) * 256;
+
+#define T3_ISSUE(kt_)                                                                                     \
+    {                                                                                                     \
+        const unsigned sb_ = smem_base + ((kt_) & (T3_STAGES - 1)) * T3_STAGE_BYTES + dma_off;            \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
+            const int m_ = min(m_begin + (kt_) * T3_BK + prow0 + 4 * j, m_end - 1); /* tail rows: zeroed in LDS below */ \
+            glds16(gsrc + (size_t)m_ * ld + lc8[j], sb_ + j * 1024);                                      \
+        }                                                                                                 \
+    }
+
+    for (int st = 0; st < T3_STAGES - 1; ++st)
+        if (st < nk) T3_ISSUE(st)
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read lane addressing inside an image: lane supplies (row = 8h + (li>>2) [+4], cols = base + 16*g1 + 4*(li&3))
+    const int trow = 8 * h + (li >> 2);
+    int offA[3], offB[2];  // byte offset of (image, column) for this wave's MFMA blocks, row 0
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = 96 * wp + 32 * i + 16 * g1 + 4 * (li & 3);  // column inside the 384-wide Y tile
+        offA[i] = (c >> 7) * T3_IMG + (c & 127);                  // image byte base + column (resolved per row below)
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) offB[j] = 3 * T3_IMG + (64 * wq + 32 * j + 16 * g1 + 4 * (li & 3));
+    auto tr_off = [](int imgcol, int row) {  // imgcol = image byte base + column (column < 128)
+        const int base = imgcol & ~127, col = imgcol & 127;
+        return base + lds128_off(row, col);
+    };
+
+    // bias gradient: workgroups of the first Q tile add up their Y images (48 column chunks x 10 row groups)
+    const bool do_bias = (a.dbias != nullptr) && (tq == 0);
+    const int bch = tid % 48, brg = tid / 48;  // threads >= 480 idle for this
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + T3_STAGES - 1 < nk) T3_ISSUE(kt + T3_STAGES - 1)
+        char* st = smem + (kt & (T3_STAGES - 1)) * T3_STAGE_BYTES;
+        if (kt == nk - 1 && last_valid < T3_BK) {  // ragged end of the reduction: rows that do not exist must contribute 0
+            const int nbad = T3_BK - last_valid;
+            for (int idx = tid; idx < nbad * 64; idx += 512) {
+                const int r = last_valid + idx / 64, im = (idx & 63) >> 4, ch = idx & 15;
+                lds_write128(st, im * T3_IMG + r * 256 + ch * 16, make_uint4(0, 0, 0, 0));
+            }
+            __syncthreads();
+        }
+#if DCV_TABL != 2
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row0 = 16 * ks + trow;
+            bf16x8 af[3], bf[2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) af[i] = join4(lds_tr_read(st, tr_off(offA[i], row0)), lds_tr_read(st, tr_off(offA[i], row0 + 4)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = join4(lds_tr_read(st, tr_off(offB[j], row0)), lds_tr_read(st, tr_off(offB[j], row0 + 4)));
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+#else
+        asm volatile("" ::"v"(st));
+#endif
+        if (do_bias && brg < 10) {
+            const int im = bch >> 4, ci = bch & 15;
+            for (int r = brg; r < T3_BK; r += 10) {
+                const int pc = ((((ci >> 2) ^ (r & 3)) << 2) | (ci & 3));
+                const uint4 v = lds_read128(st, im * T3_IMG + r * 256 + pc * 16);
+                bs[0] += __uint_as_float(v.x << 16); bs[1] += __uint_as_float(v.x & 0xffff0000u);
+                bs[2] += __uint_as_float(v.y << 16); bs[3] += __uint_as_float(v.y & 0xffff0000u);
+                bs[4] += __uint_as_float(v.z << 16); bs[5] += __uint_as_float(v.z & 0xffff0000u);
+                bs[6] += __uint_as_float(v.w << 16); bs[7] += __uint_as_float(v.w & 0xffff0000u);
+            }
+        }
+    }
+#undef T3_ISSUE
+#if DCV_TABL == 1
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (a.M > 0) return;
+#endif
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + wq * 64 + j * 32 + r32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + wp * 96 + i * 32 + acc_row(r, h);
+                atomicAdd(a.dW + (size_t)p * a.lddw + q, acc[i][j][r]);
+            }
+        }
+    if (do_bias) {
+        __syncthreads();  // all stage reads are done: reuse the ring for the 10 x 384 partial sums
+        float* red = reinterpret_cast<float*>(smem);
+        if (brg < 10) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(brg * 48 + bch) * 8 + e] = bs[e];
+        }
+        __syncthreads();
+        if (tid < 384) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 10; ++g) sum += red[g * 384 + tid];
+            atomicAdd(a.dbias + p0 + tid, sum);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue,
@@ -546,6 +712,22 @@ extern "C" int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, i
     if (!Y || !X || !dW) return DCV_ERR_NULL;
     if (M <= 0 || P <= 0 || Q <= 0 || (P % 8) || (Q % 8)) return DCV_ERR_SHAPE;
     if ((ldy % 8) || (ldx % 8) || ((uintptr_t)Y & 15) || ((uintptr_t)X & 15)) return DCV_ERR_ALIGN;
+    // measured (M = 100 416): 1152x384 158 -> 140 us, 1536x384 206 -> 176, 384x1536 203 -> 182, but 384x384 63 -> 79
+    // (3 tiles x 85 splits: the fp32 atomic traffic grows faster than the operand traffic shrinks)
+    const char* small_env = getenv("DCV_TN_SMALL_TILE");
+    if ((P % 384) == 0 && (Q % 128) == 0 && (P / 384) * (Q / 128) >= 6 && !(small_env && small_env[0])) {
+        const int tiles3 = (P / 384) * (Q / 128);
+        int splits3 = 256 / tiles3;  // one 128 KB workgroup per CU, one resident round
+        const int max3 = (M + T3_BK - 1) / T3_BK;
+        if (splits3 > max3) splits3 = max3;
+        if (splits3 < 1) splits3 = 1;
+        const int mps3 = ((M + splits3 - 1) / splits3 + T3_BK - 1) / T3_BK * T3_BK;
+        splits3 = (M + mps3 - 1) / mps3;
+        GemmTnArgs a3{(const bf16_t*)Y, ldy, (const bf16_t*)X, ldx, M, P, Q, dW, lddw, dbias, mps3, splits3};
+        hipLaunchKernelGGL(gemm_tn384_kernel, dim3(tiles3 * splits3), dim3(512), 0, (hipStream_t)stream, a3);
+        DCV_LAUNCH_CHECK();
+        return DCV_OK;
+    }
     const int tiles = ((P + 127) / 128) * ((Q + 127) / 128);
     // one resident round: 2 workgroups per CU (64 KB LDS each) x 256 CUs = 512 slots; a 513th workgroup would run
     // alone in a second round and double the launch time.  Every split is a multiple of BK rows.

@@ -24,6 +24,10 @@ r["attn_bwd_us"]=t(lambda: hip.attn_bwd(qkv,o,dO,lse,delta,dqkv,B,N,H,64,0.125))
 r["gemm_qkv_us"]=t(lambda: hip.gemm_nt(A,W,hip.EPI_BIAS_BF16,out,bias=bias))
 r["gemm_fc1_us"]=t(lambda: hip.gemm_nt(A,W1,hip.EPI_BIAS_GELU_BF16,z,bias=b1,out2=hh))
 r["gemm_tn_qkv_us"]=t(lambda: hip.gemm_tn_acc(out,A,dW,db))
+dWp=torch.zeros(D,D,device="cuda"); dW1=torch.zeros(4*D,D,device="cuda"); dW2=torch.zeros(D,4*D,device="cuda"); db1=torch.zeros(4*D,device="cuda"); dbp=torch.zeros(D,device="cuda")
+r["gemm_tn_proj_us"]=t(lambda: hip.gemm_tn_acc(A,A,dWp,dbp))
+r["gemm_tn_fc1_us"]=t(lambda: hip.gemm_tn_acc(z,A,dW1,db1))
+r["gemm_tn_fc2_us"]=t(lambda: hip.gemm_tn_acc(A,z,dW2,dbp))
 Wp=torch.randn(D,D,device="cuda").to(torch.bfloat16)*0.05; bp=torch.zeros(D,device="cuda"); xr=torch.randn(M,D,device="cuda"); xo=torch.empty_like(xr)
 r["gemm_proj_resid_us"]=t(lambda: hip.gemm_nt(A,Wp,hip.EPI_BIAS_RESID_F32,xo,bias=bp,aux=xr))
 W2=torch.randn(D,4*D,device="cuda").to(torch.bfloat16)*0.05
