@@ -15,9 +15,14 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, const int* __restrict__ ch_idx,
+// IN = float (already-normalised images, the reference's batch format) or uint8_t (raw pixels: the per-channel
+// (x*scale[c] + shift[c]) normalisation of the CPU data pipeline is fused here); scale/shift are
+// indexed by the GATHERED channel position c (the caller gathers them like channel_embed) and may be null.
+template <typename IN>
+__global__ __launch_bounds__(256) void im2col_kernel(const IN* __restrict__ x, const int* __restrict__ ch_idx,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                      bf16_t* __restrict__ out, int B, int Ct, int C, int H, int W, int P) {
-    // one thread per float4 of the gathered image: (b, c, y, x4)
+    // one thread per 4 pixels of the gathered image: (b, c, y, x4)
     const int W4 = (W / P) * P / 4;  // only full patches
     const int Hh = (H / P) * P;
     const size_t total = (size_t)B * C * Hh * W4;
@@ -30,7 +35,18 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x
         r /= Hh;
         int c = r % C;
         int b = r / C;
-        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)b * Ct + ch_idx[c]) * H + y) * W + x4 * 4);
+        const IN* src = x + (((size_t)b * Ct + ch_idx[c]) * H + y) * W + x4 * 4;
+        float4 v;
+        if constexpr (sizeof(IN) == 1) {
+            const uchar4 u = *reinterpret_cast<const uchar4*>(src);
+            v = make_float4((float)u.x, (float)u.y, (float)u.z, (float)u.w);
+        } else {
+            v = *reinterpret_cast<const float4*>(src);
+        }
+        if (scale) {
+            const float sc = scale[c], sh = shift ? shift[c] : 0.f;
+            v = make_float4(v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh);
+        }
         int pj = (x4 * 4) / P, vv = (x4 * 4) % P;
         int pi = y / P, u = y % P;
         size_t row = ((size_t)b * C + c) * (hp * wp) + pi * wp + pj;
@@ -273,13 +289,19 @@ extern "C" int dcv_gather_tokens(const float* x, const int* idx, float* out, int
     return DCV_OK;
 }
 
-extern "C" int dcv_im2col_bf16(const float* x, const int* ch_idx, void* out, int B, int Ct, int C, int H, int W, int P, void* stream) {
+extern "C" int dcv_im2col_bf16(const void* x, int x_is_u8, const int* ch_idx, const float* scale, const float* shift, void* out, int B,
+                               int Ct, int C, int H, int W, int P, void* stream) {
     if (!x || !ch_idx || !out) return DCV_ERR_NULL;
     if (B <= 0 || C <= 0 || Ct <= 0 || P <= 0 || (P & 3) || (W & 3) || H < P || W < P) return DCV_ERR_SHAPE;
     size_t total = (size_t)B * C * ((H / P) * P) * ((W / P) * P / 4);
     size_t grid = (total + 255) / 256;
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, ch_idx, (bf16_t*)out, B, Ct, C, H, W, P);
+    if (x_is_u8)
+        hipLaunchKernelGGL(im2col_kernel<unsigned char>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)x,
+                           ch_idx, scale, shift, (bf16_t*)out, B, Ct, C, H, W, P);
+    else
+        hipLaunchKernelGGL(im2col_kernel<float>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, ch_idx, scale,
+                           shift, (bf16_t*)out, B, Ct, C, H, W, P);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

@@ -204,7 +204,8 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, ch_idx_dev, C, want_ortho, keep, x, E, pos_tab, *params):
-        st = model._run_forward(x, ch_idx_dev, C, E, pos_tab, want_ortho, save=any(ctx.needs_input_grad), keep=keep)
+        st = model._run_forward(x, ch_idx_dev, C, E, pos_tab, want_ortho, save=any(ctx.needs_input_grad), keep=keep,
+                                st_scale=model._cur_scale, st_shift=model._cur_shift)
         ctx.model = model
         ctx.st = st
         return st["feat"], st["stats"]
@@ -251,6 +252,7 @@ class DiChaViT(nn.Module):
         self._R_cache: Dict = {}
         self._idx_cache: Dict = {}
         self.hcs_sampler = None  # optional callable(model, chunk_name, cur_channels) -> (picked ids, positions): pins the subset
+        self._in_scale = self._in_shift = None  # optional per-global-channel input affine (set_input_normalisation)
 
     # ---------------------------------------------------------------------------------------
     # arena management
@@ -338,6 +340,16 @@ class DiChaViT(nn.Module):
     # ---------------------------------------------------------------------------------------
     # host-side pieces of PatchEmbedPerChannel.forward (dichavit.py:110-417)
     # ---------------------------------------------------------------------------------------
+    def set_input_normalisation(self, mean, std, max_pixel_value: float = 255.0):
+        """Optional: feed RAW images (uint8 or float) and let the tokeniser apply the data pipeline's
+        per-channel normalisation (x / max_pixel_value - mean_c) / std_c (jump_cp_transforms.py:119-121) on the fly.
+        mean/std are indexed by GLOBAL channel id (the mapper's ids).  Without this call the model expects the
+        reference's already-normalised float32 batch."""
+        mean = torch.as_tensor(mean, dtype=torch.float32)
+        std = torch.as_tensor(std, dtype=torch.float32)
+        self._in_scale = 1.0 / (max_pixel_value * std)
+        self._in_shift = -mean / std
+
     def _index_tensor(self, values, dtype, device):
         """Small index lists live on the device once (no host->device copy per step; graph-capture safe)."""
         key = (tuple(values), dtype, str(device))
@@ -465,7 +477,7 @@ class DiChaViT(nn.Module):
     # ---------------------------------------------------------------------------------------
     # forward / backward drivers (kernel sequences)
     # ---------------------------------------------------------------------------------------
-    def _run_forward(self, x, ch_idx_dev, C, E, pos_tab, want_ortho, save, keep=None):
+    def _run_forward(self, x, ch_idx_dev, C, E, pos_tab, want_ortho, save, keep=None, st_scale=None, st_shift=None):
         fe = self.feature_extractor
         D, H = self.dim, fe.num_heads
         P = fe.patch_size
@@ -480,7 +492,7 @@ class DiChaViT(nn.Module):
         st = dict(B=B, C=C, n=n, N=N, M=M, save=save)
         # --- tokeniser: im2col -> MFMA GEMM with (+bias +channel_embed[c] +pos[i]) epilogue ---
         Xp = torch.empty(B * T, P * P, dtype=bf, device=dev)
-        hip.im2col(x, ch_idx_dev, Xp, B, Ct, C, Hi, Wi, P)
+        hip.im2col(x, ch_idx_dev, Xp, B, Ct, C, Hi, Wi, P, scale=st_scale, shift=st_shift)
         xs = torch.empty(B, N, D, dtype=f32, device=dev)
         Y = torch.empty(B * T, D, dtype=f32, device=dev) if want_ortho else None
         Ec, pc = E.contiguous(), pos_tab.contiguous()
@@ -633,7 +645,9 @@ class DiChaViT(nn.Module):
         pe = fe.patch_embed
         cfg = self.cfg
         self._ensure_arena(x.device)
-        x = x.contiguous().float()
+        x = x.contiguous() if x.dtype == torch.uint8 else x.contiguous().float()
+        if x.dtype == torch.uint8 and self._in_scale is None:
+            raise ValueError("uint8 images need set_input_normalisation(mean, std) (the reference feeds normalised float32)")
         B, Cin, Hi, Wi = x.shape
         cur_channels = list(pe.mapper[chunk_name])  # dichavit.py:120
         if Cin != len(cur_channels):
@@ -655,6 +669,11 @@ class DiChaViT(nn.Module):
         pos_tab = self._pos_table(C, n, Hi, Wi)
         ch_idx_dev = self._index_tensor(idx, torch.int32, x.device)
         keep = self._token_keep(C, n)
+        self._cur_scale = self._cur_shift = None
+        if self._in_scale is not None:  # gather the affine like channel_embed: by the global ids of the channels used
+            gi = self._index_tensor(cur_channels, torch.int64, x.device)
+            self._cur_scale = self._in_scale.to(x.device)[gi].contiguous()
+            self._cur_shift = self._in_shift.to(x.device)[gi].contiguous()
         feat, stats = _EncoderFn.apply(self, ch_idx_dev, C, want_ortho, keep, x, channel_embed, pos_tab, *self._enc_params)
         # --- regularisers (tiny tensors; models/loss_fn.py) ---
         extra = 0

@@ -27,7 +27,7 @@ _SIGS = {
     "dcv_attn_bwd_delta": ([_vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_attn_bwd_dq": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_dkdv": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
-    "dcv_im2col_bf16": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "dcv_im2col_bf16": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "dcv_patch_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_gather_tokens": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
     "dcv_fill_cls": ([_vp, _vp, _vp, _i, _l, _i, _vp], _i),
@@ -169,9 +169,12 @@ def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale):
     _check(rc, "dcv_attn_bwd_dkdv")
 
 
-def im2col(x, ch_idx, out, B, Ct, C, H, W, P):
-    _req(x, torch.float32, "x"); _req(ch_idx, torch.int32, "ch_idx")
-    _check(load().dcv_im2col_bf16(_p(x), _p(ch_idx), _p(out), B, Ct, C, H, W, P, _stream()), "dcv_im2col_bf16")
+def im2col(x, ch_idx, out, B, Ct, C, H, W, P, scale=None, shift=None):
+    if x.dtype not in (torch.float32, torch.uint8):
+        raise RuntimeError(f"x: expected float32 or uint8 images, got {x.dtype}")
+    _req(x, x.dtype, "x"); _req(ch_idx, torch.int32, "ch_idx")
+    _check(load().dcv_im2col_bf16(_p(x), 1 if x.dtype == torch.uint8 else 0, _p(ch_idx), _p(scale), _p(shift), _p(out), B, Ct, C, H, W,
+                                  P, _stream()), "dcv_im2col_bf16")
 
 
 def patch_bwd(dx0, dYloss, dY_bf16, dE, dpos, dcls, B, C, n, D):

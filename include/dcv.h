@@ -70,8 +70,12 @@ int dcv_attn_bwd_dq(const void* qkv, const void* dO, const float* lse, const flo
 int dcv_attn_bwd_dkdv(const void* qkv, const void* dO, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
                       int head_dim, float scale, void* stream);
 
-/* x f32 [B,Ct,H,W], ch_idx int32[C] (device) -> bf16 [B*C*(H/P)*(W/P), P*P] patch rows (dichavit.py:134/210,377). */
-int dcv_im2col_bf16(const float* x, const int* ch_idx, void* out, int B, int Ct, int C, int H, int W, int P, void* stream);
+/* x [B,Ct,H,W] f32 (x_is_u8 == 0: normalised images, the reference's batch format) or u8 (raw pixels), ch_idx int32[C]
+ * (device) -> bf16 [B*C*(H/P)*(W/P), P*P] patch rows (dichavit.py:134/210,377).  scale/shift f32[C] (nullable, indexed by
+ * gathered position): x*scale[c] + shift[c], i.e. the (x/255 - mean_c)/std_c of the CPU pipeline
+ * (jump_cp_transforms.py:119-121) fused into the tokeniser. */
+int dcv_im2col_bf16(const void* x, int x_is_u8, const int* ch_idx, const float* scale, const float* shift, void* out, int B, int Ct,
+                    int C, int H, int W, int P, void* stream);
 /* one pass over d(tokens) f32 [B,1+C*n,D]: dY_bf16 [B*C*n,D] = dx0[:,1:] (+ dYloss) ; dE [C,D], dpos [1+n,D], dcls [D] += */
 int dcv_patch_bwd(const float* dx0, const float* dYloss, void* dY_bf16, float* dE, float* dpos, float* dcls, int B, int C, int n,
                   int D, void* stream);

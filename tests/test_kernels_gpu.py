@@ -188,6 +188,16 @@ def test_im2col(hip):
     out = torch.empty(B * 8 * 196, 256, dtype=torch.bfloat16, device="cuda")
     hip.im2col(x, idx, out, B, Ct, 8, H, H, P)
     assert torch.equal(out.cpu(), orc.unfold_patches(x.cpu(), P).reshape(-1, 256).to(torch.bfloat16))
+    # raw uint8 pixels with the per-channel affine fused (gathered channel order)
+    B, Ct, H, P = 2, 5, 32, 8
+    raw = torch.randint(0, 256, (B, Ct, H, H), dtype=torch.uint8, device="cuda")
+    idx = torch.tensor([3, 1], dtype=torch.int32, device="cuda")
+    scale, shift = torch.tensor([0.02, 0.05], device="cuda"), torch.tensor([-1.5, 0.25], device="cuda")
+    out = torch.empty(B * 2 * 16, 64, dtype=torch.bfloat16, device="cuda")
+    hip.im2col(raw, idx, out, B, Ct, 2, H, H, P, scale=scale, shift=shift)
+    xn = raw[:, idx.long()].float() * scale[None, :, None, None] + shift[None, :, None, None]
+    ref = orc.unfold_patches(xn.cpu(), P).reshape(-1, 64)
+    assert (out.cpu().float() - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("B,C,n,D", [(3, 5, 16, 384), (2, 1, 9, 192), (4, 8, 49, 768)])

@@ -409,3 +409,35 @@ def test_token_drop_parity(gpu_device):
         model.eval()
         with torch.inference_mode():
             assert model(x.to(gpu_device), "train", None).shape == (2, 6)
+
+
+def test_fused_input_normalisation(gpu_device):
+    """raw uint8 pixels + set_input_normalisation(mean, std) give the same forward/backward as the
+    reference's batch format (float32 already normalised on the CPU as (x/255 - mean_c)/std_c), incl. a chunk whose
+    channels are a non-identity subset of the global ids."""
+    import diverse_channel_vit_amd as dcv
+    meta, _ = load_golden("chammi")
+    rs = np.random.RandomState(5)
+    mean = rs.uniform(0.02, 0.3, 12).astype(np.float32)
+    std = rs.uniform(0.05, 0.2, 12).astype(np.float32)
+    ch = meta["mapper"]["HPA"]  # global ids [3,4,5,6]
+    raw = torch.from_numpy(rs.randint(0, 256, (2, 4, 64, 64)).astype(np.uint8))
+    ref_in = (raw.float() / 255.0 - torch.from_numpy(mean[ch])[None, :, None, None]) / torch.from_numpy(std[ch])[None, :, None, None]
+    outs = []
+    for fused in (False, True):
+        model, _ = build(meta, gpu_device)
+        if fused:
+            model.set_input_normalisation(mean, std, 255.0)
+            x = raw.to(gpu_device)
+        else:
+            x = ref_in.to(gpu_device)
+        feat, extra = model(x, "HPA", init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        (feat.square().mean() + extra).backward()
+        outs.append((feat.detach().clone(), extra.item(), model.feature_extractor.patch_embed.proj.weight.grad.detach().clone()))
+    (f0, e0, g0), (f1, e1, g1) = outs
+    assert (f0 - f1).abs().max().item() <= 2e-2 * f0.abs().max().item()
+    assert abs(e0 - e1) <= 1e-3 * abs(e0) + 1e-6
+    assert (g0 - g1).norm().item() <= 2e-2 * g0.norm().item()
+    model, _ = build(meta, gpu_device)
+    with pytest.raises(ValueError):
+        model(raw.to(gpu_device), "HPA")
