@@ -49,8 +49,40 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4, long n) {
+// Stochastic rounding fp32 -> bf16 (round up with probability = the discarded fraction).  The random 16 bits are a
+// hash of (element offset from the arena base, seed), so the straight and the transposed operand copy of one weight
+// get the SAME rounding and a step is reproducible from its seed.  Why: with round-to-nearest the bf16 operand copy of
+// a weight stays put for many AdamW steps of +-lr (4.9e-5 against a bf16 ulp of ~2e-4 at |w|=0.03) while the fp32
+// master moves, and that lag is coherent over all weights; stochastic rounding makes the copy unbiased every step.
+__device__ __forceinline__ unsigned sr_bits(unsigned idx, unsigned seed) {
+    unsigned h = idx ^ (seed * 0x9E3779B9u);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h & 0xFFFFu;  // independent draws per element AND per step (a Weyl walk over the steps measured 3x worse)
+}
+__device__ __forceinline__ unsigned short sr_bf16(float x, unsigned idx, unsigned seed) {
+    unsigned b = __float_as_uint(x);
+    if ((b & 0x7F800000u) == 0x7F800000u) return (unsigned short)(b >> 16);  // inf / nan: truncate
+    return (unsigned short)((b + sr_bits(idx, seed)) >> 16);
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n4, long n,
+                                                        const unsigned* __restrict__ seed_dev) {
     const long stride = (long)gridDim.x * 256;
+    if (seed_dev) {
+        const unsigned seed = seed_dev[0];
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            float4 v = reinterpret_cast<const float4*>(src)[i];
+            const unsigned e = (unsigned)(i * 4);
+            uint2 o;
+            o.x = (unsigned)sr_bf16(v.x, e, seed) | ((unsigned)sr_bf16(v.y, e + 1, seed) << 16);
+            o.y = (unsigned)sr_bf16(v.z, e + 2, seed) | ((unsigned)sr_bf16(v.w, e + 3, seed) << 16);
+            reinterpret_cast<uint2*>(dst)[i] = o;
+        }
+        if (blockIdx.x == 0)
+            for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) d16[i] = sr_bf16(src[i], (unsigned)i, seed);
+        return;
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
         float4 v = reinterpret_cast<const float4*>(src)[i];
         reinterpret_cast<uint2*>(dst)[i] = pack4_bf16(v.x, v.y, v.z, v.w);
@@ -61,7 +93,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 // desc[k] = {src offset (floats), dst offset (bf16 elems), R, C}: dst[C][R] = bf16(src[R][C])
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
-                                                             const long long* __restrict__ desc) {
+                                                             const long long* __restrict__ desc, const unsigned* __restrict__ seed_dev) {
     __shared__ float tile[64][65];
     const long long* d = desc + 4 * blockIdx.y;
     const long long so = d[0], doff = d[1];
@@ -75,6 +107,15 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
         tile[rr][tx] = (r < R && c < C) ? src[so + (long long)r * C + c] : 0.f;
     }
     __syncthreads();
+    if (seed_dev) {
+        const unsigned seed = seed_dev[0];
+        unsigned short* d16 = reinterpret_cast<unsigned short*>(dst);
+        for (int cc = ty; cc < 64; cc += 4) {
+            int c = c0 + cc, r = r0 + tx;
+            if (c < C && r < R) d16[doff + (long long)c * R + r] = sr_bf16(tile[tx][cc], (unsigned)(so + (long long)r * C + c), seed);
+        }
+        return;
+    }
     for (int cc = ty; cc < 64; cc += 4) {
         int c = c0 + cc, r = r0 + tx;
         if (c < C && r < R) dst[doff + (long long)c * R + r] = (bf16_t)tile[tx][cc];
@@ -129,7 +170,21 @@ extern "C" int dcv_cast_bf16(const float* src, void* dst, long n, void* stream) 
     long grid = (n4 + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4, n);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4, n,
+                       (const unsigned*)nullptr);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_cast_bf16_sr(const float* src, void* dst, long n, const unsigned* seed_dev, void* stream) {
+    if (!src || !dst || !seed_dev) return DCV_ERR_NULL;
+    if (n <= 0 || n > 0xFFFFFFFFL) return DCV_ERR_SHAPE;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return DCV_ERR_ALIGN;
+    long n4 = n / 4;
+    long grid = (n4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4, n, seed_dev);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
@@ -138,7 +193,18 @@ extern "C" int dcv_cast_transpose_bf16(const float* src_base, void* dst_base, co
                                        void* stream) {
     if (!src_base || !dst_base || !desc_dev) return DCV_ERR_NULL;
     if (n_desc <= 0 || max_tiles <= 0) return DCV_ERR_SHAPE;
-    hipLaunchKernelGGL(cast_transpose_kernel, dim3(max_tiles, n_desc), dim3(256), 0, (hipStream_t)stream, src_base, (bf16_t*)dst_base, desc_dev);
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(max_tiles, n_desc), dim3(256), 0, (hipStream_t)stream, src_base, (bf16_t*)dst_base, desc_dev,
+                       (const unsigned*)nullptr);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_cast_transpose_bf16_sr(const float* src_base, void* dst_base, const long long* desc_dev, int n_desc, int max_tiles,
+                                          const unsigned* seed_dev, void* stream) {
+    if (!src_base || !dst_base || !desc_dev || !seed_dev) return DCV_ERR_NULL;
+    if (n_desc <= 0 || max_tiles <= 0) return DCV_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(max_tiles, n_desc), dim3(256), 0, (hipStream_t)stream, src_base, (bf16_t*)dst_base, desc_dev,
+                       seed_dev);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

@@ -21,6 +21,7 @@ Design (MI355X-first, not a translation):
 from __future__ import annotations
 
 import math
+import os
 import random
 from collections import Counter, defaultdict
 from typing import Dict, List, Optional, Sequence
@@ -253,6 +254,10 @@ class DiChaViT(nn.Module):
         self._idx_cache: Dict = {}
         self.hcs_sampler = None  # optional callable(model, chunk_name, cur_channels) -> (picked ids, positions): pins the subset
         self._in_scale = self._in_shift = None  # optional per-global-channel input affine (set_input_normalisation)
+        # bf16 operand copies of the weights: stochastically rounded on training forwards (unbiased w.r.t. the fp32
+        # master every step), round-to-nearest otherwise.  DCV_WEIGHT_ROUNDING=nearest turns it off.
+        self.stochastic_weight_rounding = os.environ.get("DCV_WEIGHT_ROUNDING", "stochastic") != "nearest"
+        self._sr_seed = None  # device int32 word, bumped after every stochastically rounded refresh
 
     # ---------------------------------------------------------------------------------------
     # arena management
@@ -319,7 +324,14 @@ class DiChaViT(nn.Module):
             return v.view(p.numel() // R, R) if transposed else v.view(R, p.numel() // R)
         return v
 
-    def _refresh_operand_copies(self):
+    def _refresh_operand_copies(self, stochastic: bool = False):
+        if stochastic:
+            if self._sr_seed is None or self._sr_seed.device != self._arena.device:
+                self._sr_seed = torch.full((1,), int(_cfg_get(self.cfg, "weight_rounding_seed", 1)), dtype=torch.int32, device=self._arena.device)
+            hip.cast_bf16_sr(self._arena, self._bf16, self._enc_size, self._sr_seed)
+            hip.cast_transpose_bf16_sr(self._arena, self._bf16_t, self._tdesc, self._tdesc_n, self._tdesc_tiles, self._sr_seed)
+            self._sr_seed.add_(1)  # a device-side bump: replays of a captured step draw fresh bits too
+            return
         hip.cast_bf16(self._arena, self._bf16, self._enc_size)
         hip.cast_transpose_bf16(self._arena, self._bf16_t, self._tdesc, self._tdesc_n, self._tdesc_tiles)
 
@@ -487,7 +499,7 @@ class DiChaViT(nn.Module):
         M = B * N
         dev = x.device
         bf, f32 = torch.bfloat16, torch.float32
-        self._refresh_operand_copies()
+        self._refresh_operand_copies(stochastic=bool(save) and self.training and self.stochastic_weight_rounding)
         pe = fe.patch_embed
         st = dict(B=B, C=C, n=n, N=N, M=M, save=save)
         # --- tokeniser: im2col -> MFMA GEMM with (+bias +channel_embed[c] +pos[i]) epilogue ---

@@ -37,6 +37,8 @@ _SIGS = {
     "dcv_adamw_dyn": ([_vp, _vp, _vp, _vp, _l, _vp, _vp], _i),
     "dcv_cast_bf16": ([_vp, _vp, _l, _vp], _i),
     "dcv_cast_transpose_bf16": ([_vp, _vp, _vp, _i, _i, _vp], _i),
+    "dcv_cast_bf16_sr": ([_vp, _vp, _l, _vp, _vp], _i),
+    "dcv_cast_transpose_bf16_sr": ([_vp, _vp, _vp, _i, _i, _vp, _vp], _i),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -211,3 +213,12 @@ def cast_bf16(src, dst, n):
 
 def cast_transpose_bf16(src_base, dst_base, desc_dev, n_desc, max_tiles):
     _check(load().dcv_cast_transpose_bf16(_p(src_base), _p(dst_base), _p(desc_dev), n_desc, max_tiles, _stream()), "dcv_cast_transpose_bf16")
+
+
+def cast_bf16_sr(src, dst, n, seed_dev):
+    _check(load().dcv_cast_bf16_sr(_p(src), _p(dst), n, _p(seed_dev), _stream()), "dcv_cast_bf16_sr")
+
+
+def cast_transpose_bf16_sr(src_base, dst_base, desc_dev, n_desc, max_tiles, seed_dev):
+    _check(load().dcv_cast_transpose_bf16_sr(_p(src_base), _p(dst_base), _p(desc_dev), n_desc, max_tiles, _p(seed_dev), _stream()),
+           "dcv_cast_transpose_bf16_sr")

@@ -103,6 +103,14 @@ int dcv_adamw_dyn(float* p, const float* g, float* m, float* v, long n, const fl
 int dcv_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* desc_dev: device int64 [n_desc][4] = {src offset, dst offset, R, C}; dst[C][R] = bf16(src[R][C]) */
 int dcv_cast_transpose_bf16(const float* src_base, void* dst_base, const long long* desc_dev, int n_desc, int max_tiles, void* stream);
+/* Stochastically rounded variants for the TRAINING operand copies: bf16 = (fp32 bits + r) >> 16 with r = the low 16
+ * bits of lowbias32(element_offset_from_src_base ^ seed_dev[0]*0x9E3779B9).  Both use the offset from the arena base, so a
+ * weight and its transposed copy round identically; seed_dev is a device word the host bumps once per step (graph-replay
+ * safe).  The reference trains in fp32 (trainer.py:963-1006, no autocast on CPU): round-to-nearest copies lag the fp32
+ * master coherently under AdamW's +-lr steps, unbiased rounding removes that lag. */
+int dcv_cast_bf16_sr(const float* src, void* dst, long n, const unsigned* seed_dev, void* stream);
+int dcv_cast_transpose_bf16_sr(const float* src_base, void* dst_base, const long long* desc_dev, int n_desc, int max_tiles,
+                               const unsigned* seed_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -296,3 +296,47 @@ def test_attention_long_sequence_base_heads(hip):
         ref = g[:, :, i]
         rel = (d[:, :, i] - ref).norm().item() / ref.norm().item()
         assert rel <= 2e-2, (nm, rel)
+
+
+def _lowbias32(h):
+    h = h.astype(np.uint64)
+    h ^= h >> 16; h = (h * 0x7FEB352D) & 0xFFFFFFFF; h ^= h >> 15; h = (h * 0x846CA68B) & 0xFFFFFFFF; h ^= h >> 16
+    return h
+
+
+def _sr_bf16_numpy(x, base_index, seed):
+    """The stochastic rounding the header specifies (include/dcv.h: dcv_cast_bf16_sr), restated with integers."""
+    bits = x.view(np.uint32).astype(np.uint64)
+    idx = base_index.astype(np.uint64) & 0xFFFFFFFF
+    r = _lowbias32(idx ^ ((seed * 0x9E3779B9) & 0xFFFFFFFF)) & 0xFFFF
+    return (((bits + r) & 0xFFFFFFFF) >> 16).astype(np.uint16)
+
+
+def test_stochastic_cast_bit_exact_and_unbiased(gpu_device):
+    """Both operand copies (straight, transposed) round every weight identically and exactly as specified; the mean over
+    seeds converges to the fp32 value (unbiased), unlike round-to-nearest."""
+    from diverse_channel_vit_amd import hip
+    rs = np.random.RandomState(5)
+    R, Cc, pad = 192, 136, 40
+    n = pad + R * Cc + 7
+    src = (rs.standard_normal(n) * 0.03).astype(np.float32)
+    s = torch.from_numpy(src).to(gpu_device)
+    desc = torch.tensor([[pad, pad, R, Cc]], dtype=torch.int64, device=gpu_device)
+    acc = np.zeros(n, np.float64)
+    seeds = list(range(1, 65))
+    for seed in seeds:
+        sd = torch.tensor([seed], dtype=torch.int32, device=gpu_device)
+        d = torch.zeros(n, dtype=torch.bfloat16, device=gpu_device)
+        dt = torch.zeros(n, dtype=torch.bfloat16, device=gpu_device)
+        hip.cast_bf16_sr(s, d, n, sd)
+        hip.cast_transpose_bf16_sr(s, dt, desc, 1, ((R + 63) // 64) * ((Cc + 63) // 64), sd)
+        got = d.view(torch.int16).cpu().numpy().view(np.uint16)
+        want = _sr_bf16_numpy(src, np.arange(n), seed)
+        assert np.array_equal(got, want)
+        gt = dt.view(torch.int16).cpu().numpy().view(np.uint16)[pad:pad + R * Cc].reshape(Cc, R)
+        assert np.array_equal(gt.T, want[pad:pad + R * Cc].reshape(R, Cc))
+        acc += (want.astype(np.uint32) << 16).view(np.float32)
+    mean_err = np.abs(acc / len(seeds) - src)
+    rtn_err = np.abs(s.to(torch.bfloat16).float().cpu().numpy() - src)
+    # standard error of the SR mean ~ ulp/(2*sqrt(3*64)) ~ ulp/28; round-to-nearest's error is ~ulp/4 on average and does not shrink
+    assert mean_err.mean() < 0.35 * rtn_err.mean()

@@ -133,12 +133,17 @@ def test_hcs_subsets_parity(gpu_device):
     assert sorted(model.feature_extractor.patch_embed.counter.keys()) == sorted(a["d2_picked"].tolist())
 
 
-def test_chammi_chunks_parity(gpu_device):
+@pytest.mark.parametrize("rounding", ["nearest", "stochastic"])
+def test_chammi_chunks_parity(gpu_device, rounding):
     """Three forward/backward passes with 3/4/5 channels (different sequence lengths), gradients
-    accumulate across them (trainer.py:846-935); features out; proxy main loss."""
+    accumulate across them (trainer.py:846-935); features out; proxy main loss.  The proxy logits multiply the
+    feature error by 1/temperature = 14, so the single-pass loss tolerance is 1e-2 with round-to-nearest weight
+    copies and 3e-2 (0.7 % of the loss) with the default stochastically rounded ones (twice the rounding variance
+    per pass, no bias over passes: see the loss-curve tests)."""
     import diverse_channel_vit_amd as dcv
     meta, a = load_golden("chammi")
     model, _ = build(meta, gpu_device)
+    model.stochastic_weight_rounding = rounding == "stochastic"
     shapes = orc.state_shapes(meta["cfg"], 12, meta["img"], meta["num_classes"], chammi=True)
     sd = orc.make_state(shapes, meta["seed"], dtype=torch.float64)
     for v in sd.values():
@@ -152,7 +157,7 @@ def test_chammi_chunks_parity(gpu_device):
         ref = a[f"{chunk}_feat"]
         assert np.abs(feat.detach().cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max()
         assert abs(extra.item() - float(a[f"{chunk}_extra"])) <= 2e-2 * abs(float(a[f"{chunk}_extra"])) + 1e-6
-        assert abs(loss.item() - float(a[f"{chunk}_loss"])) <= 1e-2
+        assert abs(loss.item() - float(a[f"{chunk}_loss"])) <= (3e-2 if rounding == "stochastic" else 1e-2)
         l2, _, _, _ = orc.chammi_loss(sd, x.double(), y, meta["cfg"], ch, list(range(len(ch))))
         l2.backward()
     check_grads(model, sd)
@@ -219,21 +224,11 @@ def test_plugin_contract(gpu_device):
         model(x.cpu(), "train", None)
 
 
-def test_loss_curve_100_steps(gpu_device):
-    """100 optimiser steps on the HIP path (bf16 MFMA operands, fp32 master weights, fused HipAdamW)
-    against the reference's fp32 CPU curve (tests/golden/curve100_so2sat_s.npz).
-
-    Stated tolerance.  north_star's 1e-3 is NOT met by bf16 operands in this regime and the test says
-    so: the reference curve is violent (2.78 -> 3.52 -> 2.88 -> 3.49 ... in the first steps) because
-    Adam's first updates are sign-like steps of +-lr = 4.9e-5 on every weight — less than half a bf16
-    ulp (1.2e-4) of a 0.02-magnitude weight — so the bf16 operand copies reproduce the coherent update
-    only in expectation (tools/diag_step1.py: the oracle's forward on the HIP-updated fp32 weights is
-    within 1e-3 of the reference at step 1; the bf16 forward is 3e-2 off at either weight set).
-    Asserted: |err| <= 1e-3 at step 0, <= 8e-2 anywhere (2 % of the loss scale), mean |err| <= 1.5e-2,
-    and the converged tail (last 20 steps) within 2e-3."""
+def _run_curve(gpu_device, name, stochastic):
     import diverse_channel_vit_amd as dcv
-    meta, a = load_golden("curve100_so2sat_s")
+    meta, a = load_golden(name)
     model, _ = build(meta, gpu_device)
+    model.stochastic_weight_rounding = stochastic
     opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=meta["lr"], weight_decay=meta["wd"],
                        betas=tuple(meta["betas"]), eps=meta["eps"], model=model)
     batches = [orc.make_batch(meta["seed"] + 100 + i, meta["B"], meta["n_channels"], meta["img"], meta["num_classes"]) for i in range(meta["n_batches"])]
@@ -248,13 +243,46 @@ def test_loss_curve_100_steps(gpu_device):
         loss.backward()
         opt.step()
         errs.append(abs(loss.item() - ref[s]))
-    errs = np.array(errs)
-    print(f"loss-curve |err|: step0 {errs[0]:.2e} max {errs.max():.3e} mean {errs.mean():.3e} tail20 max {errs[-20:].max():.3e}; "
-          f"final loss {loss.item():.5f} vs ref {ref[-1]:.5f}")
-    assert errs[0] <= 1e-3
-    assert errs.max() <= 8e-2
-    assert errs.mean() <= 1.5e-2
-    assert errs[-20:].max() <= 2e-3
+    return np.array(errs), ref
+
+
+def _curve_report(tag, e, ref):
+    print(f"{tag} |err|: step0 {e[0]:.2e} max {e.max():.3e} mean {e.mean():.3e} tail20 max {e[-20:].max():.3e} (ref loss {ref[0]:.3f} -> {ref[-1]:.3f})")
+
+
+def test_loss_curve_100_steps(gpu_device):
+    """100 optimiser steps on the HIP path (bf16 MFMA operands, fp32 master weights, fused HipAdamW)
+    against the reference's fp32 CPU curve (tests/golden/curve100_so2sat_s.npz: So2Sat-shaped, 18 ch, bs 8).
+
+    Stated tolerance.  north_star asks for 1e-3; with bf16 MFMA operands the measured floor is: mean |err| below
+    1e-3, the converged tail below 1e-3, single steps of the violent early curve (2.78 -> 3.52 -> 2.88 -> 3.49 ...)
+    up to ~7e-3.  tools/curve_emul.py (oracle-only experiment) shows that floor is the bf16 ACTIVATION operands:
+    exact weights + bf16 activations give max 6e-3 / mean 4.6e-4 on this curve.  The weight copies no longer
+    contribute: they are stochastically rounded every step (include/dcv.h dcv_cast_bf16_sr).  With round-to-nearest
+    copies (second run below) Adam's +-lr = 4.9e-5 sign steps are lost below the bf16 ulp, the copies lag the fp32
+    master coherently, and the curve is 10x further off (max 6e-2, mean 6e-3) — kept as a regression contrast.
+    Asserted (stochastic, default): step0 <= 3e-3, max <= 2e-2, mean <= 2e-3, last 20 steps <= 1e-3."""
+    e_sr, ref = _run_curve(gpu_device, "curve100_so2sat_s", True)
+    e_rn, _ = _run_curve(gpu_device, "curve100_so2sat_s", False)
+    _curve_report("loss-curve so2sat-s stochastic", e_sr, ref)
+    _curve_report("loss-curve so2sat-s nearest   ", e_rn, ref)
+    assert e_sr[0] <= 3e-3 and e_sr.max() <= 2e-2 and e_sr.mean() <= 2e-3 and e_sr[-20:].max() <= 1e-3
+    assert e_rn[0] <= 1e-3 and e_rn.max() <= 8e-2 and e_rn.mean() <= 1.5e-2 and e_rn[-20:].max() <= 2e-3
+    assert e_sr.mean() < 0.5 * e_rn.mean()
+
+
+def test_loss_curve_headline_architecture(gpu_device):
+    """The same 100 steps on the headline architecture: DiChaViT-S / 8 ch / 224^2 / 161 classes (bs 2, lr 4.9e-5,
+    wd 0.04; tests/golden/curve100_jumpcp_s.npz, loss 5.59 -> 0.088 so single steps move by up to 0.3).
+    Asserted (stochastic, default): step0 <= 5e-3, max <= 6e-2 (1 % of the loss scale), mean <= 6e-3, tail <= 4e-3;
+    round-to-nearest copies measured max 1.4e-1 / mean 1.4e-2 and must stay worse."""
+    e_sr, ref = _run_curve(gpu_device, "curve100_jumpcp_s", True)
+    e_rn, _ = _run_curve(gpu_device, "curve100_jumpcp_s", False)
+    _curve_report("loss-curve headline stochastic", e_sr, ref)
+    _curve_report("loss-curve headline nearest   ", e_rn, ref)
+    assert e_sr[0] <= 5e-3 and e_sr.max() <= 6e-2 and e_sr.mean() <= 6e-3 and e_sr[-20:].max() <= 4e-3
+    assert e_rn.max() <= 0.25 and e_rn.mean() <= 6e-2
+    assert e_sr.mean() < 0.5 * e_rn.mean()
 
 
 def test_graphed_step_matches_eager(gpu_device):
@@ -441,3 +469,4 @@ def test_fused_input_normalisation(gpu_device):
     model, _ = build(meta, gpu_device)
     with pytest.raises(ValueError):
         model(raw.to(gpu_device), "HPA")
+
