@@ -26,14 +26,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(name: str, defines, verbose: bool = True) -> str:
+def build_variant(name: str, defines, verbose: bool = True, flags=()) -> str:
     """A/B build of the same ABI with extra -D flags -> libdcv_hip_<name>.so (select it with DCV_LIB=...)."""
     objdir = os.path.join(HERE, "build", "variant_" + name)
     os.makedirs(objdir, exist_ok=True)
     objs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + list(flags) + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

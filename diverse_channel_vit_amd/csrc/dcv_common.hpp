@@ -144,6 +144,20 @@ __device__ __forceinline__ void glds16(const bf16_t* g, unsigned lds_wave_base) 
         : "v"(g), "s"(lds_wave_base)
         : "memory");
 }
+// same DMA with a wave-uniform base (SGPR pair) and a per-lane 32-bit byte offset: a loop that walks tiles advances the
+// base with scalar adds and keeps the lane offsets loop-invariant (no per-tile vector address arithmetic)
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+        : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }

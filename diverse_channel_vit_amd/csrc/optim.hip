@@ -122,6 +122,38 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// sum of squares of a flat fp32 range, added to *acc (one atomic per block)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n4, long n, float* __restrict__ acc) {
+    const long stride = (long)gridDim.x * 256;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+}
+
+// x *= min(1, max_norm / (sqrt(*sumsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_'s coefficient, read from device memory)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ x, long n4, long n, const float* __restrict__ sumsq, float max_norm) {
+    const float coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+    if (!(coef < 1.f)) return;
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+        reinterpret_cast<float4*>(x)[i] = v;
+    }
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) x[i] *= coef;
+}
+
 __global__ __launch_bounds__(256) void fill_cls_kernel(float* __restrict__ x, const float* __restrict__ cls,
                                                        const float* __restrict__ pos0, int B, long batch_stride, int D) {
     int i = blockIdx.x * 256 + threadIdx.x;
@@ -205,6 +237,32 @@ extern "C" int dcv_cast_transpose_bf16_sr(const float* src_base, void* dst_base,
     if (n_desc <= 0 || max_tiles <= 0) return DCV_ERR_SHAPE;
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(max_tiles, n_desc), dim3(256), 0, (hipStream_t)stream, src_base, (bf16_t*)dst_base, desc_dev,
                        seed_dev);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_sumsq_acc(const float* x, long n, float* acc, void* stream) {
+    if (!x || !acc) return DCV_ERR_NULL;
+    if (n <= 0) return DCV_ERR_SHAPE;
+    if ((uintptr_t)x & 15) return DCV_ERR_ALIGN;
+    long n4 = n / 4;
+    long grid = (n4 + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n4, n, acc);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+extern "C" int dcv_clip_scale(float* x, long n, const float* sumsq_dev, float max_norm, void* stream) {
+    if (!x || !sumsq_dev) return DCV_ERR_NULL;
+    if (n <= 0 || !(max_norm > 0.f)) return DCV_ERR_SHAPE;
+    if ((uintptr_t)x & 15) return DCV_ERR_ALIGN;
+    long n4 = n / 4;
+    long grid = (n4 + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n4, n, sumsq_dev, max_norm);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

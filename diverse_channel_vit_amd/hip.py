@@ -37,6 +37,8 @@ _SIGS = {
     "dcv_adamw_dyn": ([_vp, _vp, _vp, _vp, _l, _vp, _vp], _i),
     "dcv_cast_bf16": ([_vp, _vp, _l, _vp], _i),
     "dcv_cast_transpose_bf16": ([_vp, _vp, _vp, _i, _i, _vp], _i),
+    "dcv_sumsq_acc": ([_vp, _l, _vp, _vp], _i),
+    "dcv_clip_scale": ([_vp, _l, _vp, _f, _vp], _i),
     "dcv_cast_bf16_sr": ([_vp, _vp, _l, _vp, _vp], _i),
     "dcv_cast_transpose_bf16_sr": ([_vp, _vp, _vp, _i, _i, _vp, _vp], _i),
 }
@@ -213,6 +215,14 @@ def cast_bf16(src, dst, n):
 
 def cast_transpose_bf16(src_base, dst_base, desc_dev, n_desc, max_tiles):
     _check(load().dcv_cast_transpose_bf16(_p(src_base), _p(dst_base), _p(desc_dev), n_desc, max_tiles, _stream()), "dcv_cast_transpose_bf16")
+
+
+def sumsq_acc(x, n, acc):
+    _check(load().dcv_sumsq_acc(_p(x), n, _p(acc), _stream()), "dcv_sumsq_acc")
+
+
+def clip_scale(x, n, sumsq_dev, max_norm):
+    _check(load().dcv_clip_scale(_p(x), n, _p(sumsq_dev), float(max_norm), _stream()), "dcv_clip_scale")
 
 
 def cast_bf16_sr(src, dst, n, seed_dev):

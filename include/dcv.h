@@ -99,6 +99,11 @@ int dcv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, fl
  * 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale}.  Lets a captured HIP graph of the step be replayed while the
  * step count and the schedulers' lr / weight decay advance (the host rewrites the 32 bytes between replays). */
 int dcv_adamw_dyn(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, void* stream);
+/* Gradient clipping (trainer.py:1003-1004 -> torch.nn.utils.clip_grad_norm_, L2): dcv_sumsq_acc adds sum(x^2) of a flat fp32
+ * range to the device scalar *acc (zero it first; call once per gradient buffer); dcv_clip_scale multiplies a range by
+ * min(1, max_norm / (sqrt(*sumsq_dev) + 1e-6)).  Everything stays on the device: no host sync, graph-capturable. */
+int dcv_sumsq_acc(const float* x, long n, float* acc, void* stream);
+int dcv_clip_scale(float* x, long n, const float* sumsq_dev, float max_norm, void* stream);
 /* bf16 operand copies of the parameter arena */
 int dcv_cast_bf16(const float* src, void* dst, long n, void* stream);
 /* desc_dev: device int64 [n_desc][4] = {src offset, dst offset, R, C}; dst[C][R] = bf16(src[R][C]) */

@@ -175,6 +175,57 @@ def case_jumpcp(dichavit, loss_fn):
     _train_case(dichavit, "jumpcp_s", base_cfg(), {"train": list(range(8))}, "train", 8, 8, 224, 161, 2, 31)
 
 
+def case_resume(dichavit, loss_fn):
+    """Checkpoint/resume + gradient clipping in the reference's own flow (trainer.py:1001-1006, 1292-1328): 3 steps of
+    torch AdamW with clip_grad_norm_(0.5) on the tiny config, a checkpoint in the trainer's layout taken there
+    (model_params / optimizer_params as arrays), then 3 more steps.  The fixture holds the checkpoint's tensors, the
+    reference's parameter order, the clipped-step total norms, all 6 losses and parameter norms at the end."""
+    cfg = base_cfg(pretrained_model_name="tiny", patch_size=8)
+    mapper = {"train": [0, 1, 2]}
+    model, keys = build(dichavit, cfg, mapper, 3, 32, 5, 51)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=0.04, betas=(0.9, 0.999), eps=1e-8)
+    clip = 0.5
+    batches = [orc.make_batch(151 + i, 4, 3, 32, 5) for i in range(3)]
+    losses, norms = [], []
+    arrays = {}
+
+    def one(s):
+        x, y = batches[s % 3]
+        opt.zero_grad()
+        out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+        loss.backward()
+        tn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip)
+        opt.step()
+        losses.append(loss.item()); norms.append(float(tn))
+
+    for s in range(3):
+        one(s)
+    osd = opt.state_dict()
+    # the checkpoint's tensors themselves are NOT stored (66 MB): the test rebuilds the same trajectory from the seed,
+    # passes through a save/load in the trainer's layout at this point and must land on the same remaining losses
+    ck_layout = dict(opt_state_keys=sorted(osd["state"][min(osd["state"])].keys()), n_opt_state=len(osd["state"]),
+                     opt_state_ids=sorted(int(i) for i in osd["state"]),
+                     opt_param_ids=[int(i) for i in osd["param_groups"][0]["params"]],
+                     model_keys=list(model.state_dict().keys()))
+    for idx in (1, 2, 5, 20, 100):
+        if idx in osd["state"]:
+            arrays[f"ckpt_opt_norm/{idx}"] = np.array([osd["state"][idx]["exp_avg"].double().norm().item(),
+                                                       osd["state"][idx]["exp_avg_sq"].double().norm().item()])
+    for s in range(3, 6):
+        one(s)
+    for n_, p_ in model.named_parameters():
+        if not n_.startswith("adaptive_interface"):
+            arrays["final_norm/" + n_] = np.array(p_.detach().double().norm().item())
+    save("resume", dict(cfg=cfg, mapper=mapper, n_channels=3, img=32, num_classes=5, B=4, seed=51, lr=1e-3, wd=0.04, clip=clip,
+                        param_order=names, ck_layout=ck_layout,
+                        opt_group={k: v for k, v in osd["param_groups"][0].items() if k in ("lr", "betas", "eps", "weight_decay")}),
+         dict(losses=np.array(losses), total_norms=np.array(norms), **arrays))
+
+
 def case_hcs(dichavit, loss_fn):
     """HCS sampling (dichavit.py:127-216): seeds recorded, resulting subset recorded."""
     cfg = base_cfg(patch_size=8, enable_sample=True, hcs_sampling="lowest_cosine_prob", hcs_sampling_temp=0.1)
@@ -355,7 +406,7 @@ def case_schedules(dichavit, loss_fn):
 
 
 CASES = dict(tokendrop=case_tokendrop, resolution=case_resolution, schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
-             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp)
+             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, resume=case_resume)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

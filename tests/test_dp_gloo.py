@@ -94,3 +94,45 @@ def test_dp_reducer_gloo_world2():
         assert unused_none
         # 6 layers x 4 KB merged into >= 12 KB buckets + head + tail + 2 hooked params: fewer collectives than slices
         assert 4 <= nb <= 8, nb
+
+
+class _Fixed(torch.nn.Module):
+    """A stand-in with the plugin's forward signature: logits that make the first `k` samples of a batch correct."""
+
+    def forward(self, x, chunk_name, training_chunks=None, init_first_layer=None, new_channel_init=None):
+        out = torch.zeros(x.shape[0], 4)
+        out[torch.arange(x.shape[0]), x[:, 0].long() % 4] = 1.0
+        return out
+
+
+def _eval_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diverse_channel_vit_amd.checkpoint import evaluate
+        # rank 0: 6 samples, 4 right; rank 1: 10 samples, 3 right -> 7/16 over all ranks (not the mean of the two ratios)
+        n, right = (6, 4) if rank == 0 else (10, 3)
+        y = torch.arange(n) % 4
+        x = y.clone().float()
+        x[right:] += 1.0
+        acc = evaluate(_Fixed(), [(x[:, None], y)], "test")
+        q.put((rank, acc))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_evaluate_sums_counts_over_ranks_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for rank, acc in res:
+        assert abs(acc - 100.0 * 7 / 16) < 1e-9
