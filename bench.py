@@ -199,6 +199,7 @@ def main():
 
     if rank == 0:
         B, C, H = args.batch, args.channels, {"tiny": 3, "small": 6, "base": 12, "distill": 6}[args.arch]
+        headline = (args.arch, C, args.img, args.batch, args.classes) == ("small", 8, 224, 64, 161) and not args.hcs
         D = H * 64
         n = (args.img // 16) ** 2
         N = C * n + 1
@@ -222,6 +223,24 @@ def main():
             ach = bytes_ / (per_launch_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 4), "traffic": None, "avg_launch_ms": round(per_launch_ms, 4), "launches_timed": len(rec)}
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
+        # comes from the committed rocprofv3 --pmc passes over this same command at the headline configuration
+        # (tools/pmc_traffic.sh -> profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, per the gfx950 correction)
+        if headline and roof is not None:
+            import glob
+            files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+            if files:
+                with open(files[-1]) as f:
+                    pmc = json.load(f)
+                tot = n_l = 0.0
+                for k, v in pmc.items():
+                    if k.split("<")[0].replace("_kernel", "").rstrip("0123456789") == dominant or k.startswith(dominant + "_kernel"):
+                        tot += v["launches"] * (v["read_bytes_per_launch"] + v["written_bytes_per_launch"])
+                        n_l += v["launches"]
+                if n_l:
+                    roof["traffic"] = round(tot / n_l)
+                    roof["traffic_unit"] = "bytes/launch (HBM, PMC)"
+                    roof["traffic_source"] = "profiles/" + os.path.basename(files[-1])
         imgs = args.batch * world * args.steps / dt
         line = {
             "metric": ("train images/sec, DiChaViT-S 8ch 224^2 bs=64/GPU" if (args.arch, C, args.img, args.batch) == ("small", 8, 224, 64)
