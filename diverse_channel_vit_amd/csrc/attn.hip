@@ -95,220 +95,23 @@ __device__ __forceinline__ LaneOffs lane_offs(int lane) {
     }
     return o;
 }
-// tile: byte offset of the [64][64] tile inside `base`; blk: 32-row block (0/1)
-__device__ __forceinline__ bf16x8 frag_rows_o(const char* base, const LaneOffs& o, int tile, int blk, int ks) {
-    return as_bf16x8(lds_read128(base, o.rows[ks] + tile + blk * 4096));
-}
-__device__ __forceinline__ bf16x8 frag_cols_o(const char* base, const LaneOffs& o, int tile, int blk, int s, int dt) {
-    const int c = tile + blk * 4096 + s * 2048;
-    return join4(lds_tr_read(base, o.cols[dt][0] + c), lds_tr_read(base, o.cols[dt][1] + c));
-}
 
 // ------------------------------------------------------------------------------------------------
 // K/V ring: 4 stages x (8 KB K + 8 KB V), filled by LDS-DMA three tiles ahead (48 KB in flight per workgroup).
 // A register-staged single-tile prefetch left every key tile waiting ~1.5 us for its loads (measured: 3400 cycles
 // per tile for 512 cycles of MFMA).  Each wave issues 4 DMA instructions per stage: rows [16w,16w+16) of K and of V.
-#ifndef DCV_ABL
-#define DCV_ABL 0
-#endif
 #ifndef DCV_ABL2
-#define DCV_ABL2 0
+#define DCV_ABL2 0  // timing-only ablation: 2 = no in-loop K/V DMA
 #endif
-#ifndef DCV_KV_STAGES
-#define DCV_KV_STAGES 4
-#endif
-#ifndef DCV_FWD_WAVES
-#define DCV_FWD_WAVES 4
-#endif
-constexpr int KV_STAGES = DCV_KV_STAGES, KV_STAGE_BYTES = 16384;
-constexpr int FWD_WAVES = DCV_FWD_WAVES, FWD_QTILE = 32 * FWD_WAVES;  // query rows per workgroup: K/V re-reads scale with 1/FWD_QTILE
-constexpr int KV_DMA_PER_WAVE = 16 / FWD_WAVES;  // DMA instructions per stage per wave (8 rows x 128 B each; K: 8, V: 8)
-
-struct KvDma {
-    const bf16_t* kbase;  // K rows of this (batch, head)
-    const bf16_t* vbase;
-    size_t rs;            // row stride (elements)
-    int N, rowl;          // rowl: this lane's tile row in the wave's first 8-row piece (second piece: +8)
-    int lc8[2];           // per piece: (logical chunk this lane must fetch for its physical slot) * 8 elements
-    unsigned smem_base, wave_off;
-};
-__device__ __forceinline__ void kv_issue(const KvDma& d, int t) {
-    const unsigned sb = d.smem_base + (t % KV_STAGES) * KV_STAGE_BYTES + d.wave_off;
-#pragma unroll
-    for (int j = 0; j < KV_DMA_PER_WAVE / 2; ++j) {  // 4 waves: rows [16w,16w+16) in two 8-row pieces; 8 waves: rows [8w,8w+8)
-        const int row = min(t * 64 + d.rowl + 8 * j, d.N - 1);  // keys >= N: clamp (masked by the caller)
-        const size_t off = (size_t)row * d.rs + d.lc8[j];
-        glds16(d.kbase + off, sb + j * 1024);
-        glds16(d.vbase + off, sb + 8192 + j * 1024);
-    }
-}
-
-__global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char sKV[KV_STAGES * KV_STAGE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nqt = (a.N + FWD_QTILE - 1) / FWD_QTILE;
-    const int BH = a.B * a.H;
-    int bh, qt;
-    if ((BH & 7) == 0) {  // keep all query tiles of one (batch, head) on one XCD: K/V stay in that L2
-        int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        bh = (slot / nqt) * 8 + xcd;
-        qt = slot % nqt;
-    } else {
-        bh = blockIdx.x / nqt;
-        qt = blockIdx.x % nqt;
-    }
-    const int b = bh / a.H, hh = bh % a.H;
-    const int D = a.H * 64;
-    const size_t rs = (size_t)3 * D;  // qkv row stride (elements)
-    const bf16_t* Qb = a.qkv + (size_t)b * a.N * rs + hh * 64;
-
-    const int nt = (a.N + 63) / 64;
-    KvDma dma;
-    dma.kbase = Qb + D;
-    dma.vbase = Qb + 2 * D;
-    dma.rs = rs;
-    dma.N = a.N;
-    dma.rowl = (64 / FWD_WAVES) * wave + (lane >> 3);
-    dma.lc8[0] = ((lane & 7) ^ swz64(dma.rowl)) * 8;
-    dma.lc8[1] = ((lane & 7) ^ swz64(dma.rowl + 8)) * 8;
-    dma.smem_base = __builtin_amdgcn_readfirstlane(lds_addr(sKV));
-    dma.wave_off = (64 / FWD_WAVES) * wave * 128;
-    for (int st = 0; st < KV_STAGES - 1; ++st)
-        if (st < nt) kv_issue(dma, st);
-
-    const int q = qt * FWD_QTILE + wave * 32 + r32;  // this lane's query row
-    const int qc = min(q, a.N - 1);
-    bf16x8 qf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Qb + (size_t)qc * rs + 16 * ks + 8 * h));
-    // consume the fragments here so that hipcc's own wait for these loads sits BEFORE the tile loop: inside it, its
-    // vmcnt(0) (it does not know about the asm-issued DMAs) would drain the K/V ring on every tile
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]));
-    const LaneOffs lo = lane_offs(lane);
-
-    f32x16 o[2];
-    zero_acc(o[0]);
-    zero_acc(o[1]);
-    float m = -INFINITY, l = 0.f;
-    const float c = a.scale * LOG2E;
-
-    // one key tile; MASKED is compile-time so only the last, partial tile carries the masking code
-    auto tile = [&](auto MASKED, int t) {
-        // my 4 DMAs of stage t have landed once at most the younger stages' are outstanding
-        const int rem = nt - 1 - t;
-#if !(DCV_ABL2 & 1)
-        if (KV_STAGES >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * KV_DMA_PER_WAVE) : "memory");
-        else if (rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everyone's stage t landed; everyone is done reading stage t-1
-#endif
-#if !(DCV_ABL2 & 2)
-        if (t + KV_STAGES - 1 < nt) kv_issue(dma, t + KV_STAGES - 1);
-#endif
-        LaneOffs k = lo;  // this stage's addresses: 8 integer adds per tile, the rest are immediates
-        const int so = (t % KV_STAGES) * KV_STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) k.rows[i] += so;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            k.cols[i][0] += so + 8192;
-            k.cols[i][1] += so + 8192;
-        }
-        f32x16 s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            zero_acc(s[kb]);
-#pragma unroll
-#if DCV_ABL2 & 4
-            for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(qf[(ks + kb) & 3], qf[ks], s[kb]);
-#else
-            for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(frag_rows_o(sKV, k, 0, kb, ks), qf[ks], s[kb]);
-#endif
-        }
-        if constexpr (decltype(MASKED)::value) {  // keys >= N do not exist
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t * 64 + 32 * kb + acc_row(r, h) >= a.N) s[kb][r] = -INFINITY;
-        }
-#if DCV_ABL == 1  // ablation (timing only): no softmax arithmetic
-        float mx = m, rsum = 0.f;
-#else
-        float mx = m;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mc = mx * c;
-        float rsum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[kb][r] * c - mc);
-                s[kb][r] = p;
-                rsum += p;
-            }
-        if (__any(mx > m)) {  // wave-uniform: some row's running maximum moved -> rescale what was accumulated under the old one
-            const float alpha = __builtin_amdgcn_exp2f((m - mx) * c);  // m = -inf on the first tile -> 0
-            l *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-            m = mx;
-        }
-#endif
-        l += rsum;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                bf16x8 pf = acc_to_frag(s[kb], ss);
-#if DCV_ABL == 2  // ablation: no P.V MFMAs and no transposed V reads
-                asm volatile("" ::"v"(pf));
-#elif DCV_ABL == 3  // ablation: P.V MFMAs fed from registers (no transposed V reads)
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(qf[ss + 2 * dt], pf, o[dt]);
-#else
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(frag_cols_o(sKV, k, 0, kb, ss, dt), pf, o[dt]);
-#endif
-            }
-    };
-    using No = std::integral_constant<bool, false>;
-    using Yes = std::integral_constant<bool, true>;
-    const int nfull = a.N / 64;  // full tiles first, then at most one masked tail tile
-    for (int t = 0; t < nfull; ++t) tile(No{}, t);
-    if (nfull < nt) tile(Yes{}, nfull);
-
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.f / l;
-    if (q < a.N) {
-        bf16_t* op = a.o + ((size_t)b * a.N + q) * D + hh * 64;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 v = pack4_bf16(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g + 4 * h) = v;
-            }
-        if (h == 0) a.lse[((size_t)b * a.H + hh) * a.N + q] = m * a.scale + logf(l);
-    }
-}
+constexpr int KV_STAGES = 4, KV_STAGE_BYTES = 16384;
+constexpr int FWD_WAVES = 4, FWD_QTILE = 32 * FWD_WAVES;  // query rows per workgroup: K/V re-reads scale with 1/FWD_QTILE
+constexpr int KV_DMA_PER_WAVE = 16 / FWD_WAVES;            // DMA instructions per stage per wave (8 rows x 128 B each; K: 8, V: 8)
 
 // ------------------------------------------------------------------------------------------------
 // Forward, software-pipelined: the score MFMAs of key tile t+1 are issued BEFORE the softmax of tile t, so the matrix
 // pipe works under the softmax's VALU instructions of the same wave (counters on the first version: VALU busy 61 %, MFMA
 // busy 32 %, both at once only 14 % of the time with 1.75 resident waves per SIMD).  The softmax arithmetic is written on
 // float pairs (v_pk_fma_f32 / v_pk_add_f32: two elements per VALU issue).
-#ifndef DCV_FWD_V
-#define DCV_FWD_V 2
-#endif
 #ifndef DCV_FWD_PK
 #define DCV_FWD_PK 1  // measured: packed 421 us, scalar 428-430 us, first kernel 436-448 us (tools/ab_bench.py, headline shape)
 #endif
@@ -800,11 +603,7 @@ extern "C" int dcv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, 
     if (!o || !lse) return DCV_ERR_NULL;
     AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, nullptr, lse, nullptr, nullptr, B, N, H, scale};
     const int grid = B * H * ((N + FWD_QTILE - 1) / FWD_QTILE);
-#if DCV_FWD_V == 2
     hipLaunchKernelGGL(attn_fwd2_kernel, dim3(grid), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream, a);
-#else
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), 0, (hipStream_t)stream, a);
-#endif
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

@@ -35,7 +35,6 @@ struct GemmNtArgs {
     int ldaux;
     const float* aux2;
     int T, n;
-    int stagger;  // experiment knob (DCV_NT_STAGGER): units of 1024 clocks that every other CU waits before its first tile
 };
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7: far below the bf16 rounding of the outputs), sharing
@@ -231,8 +230,6 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
 
     int L = pos;
     if (L >= total) return;
-    if (a.stagger > 0 && (blockIdx.x & 8))
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     NtTile cur, nxt;
     nt_tile_setup(a, L, tiles_n, wave, lane, cur);
     int g = 0;  // global stage counter of this workgroup: stage g lives in ring buffer g % 3
@@ -675,9 +672,9 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     if (!A || !W || !out) return DCV_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
-    static const int stagger = getenv("DCV_NT_STAGGER") ? atoi(getenv("DCV_NT_STAGGER")) : 0;
-    static const int grid_cap = getenv("DCV_NT_GRID") ? atoi(getenv("DCV_NT_GRID")) : 256;
-    GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n, stagger};
+    // DCV_NT_GRID: measurement knob (tools/stagger_probe.sh runs the persistent kernel on fewer CUs); default = every CU
+    static const int grid_cap = (getenv("DCV_NT_GRID") && atoi(getenv("DCV_NT_GRID")) > 0) ? atoi(getenv("DCV_NT_GRID")) : 256;
+    GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n};
     int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
     if (grid > grid_cap) grid = grid_cap;  // persistent: one 144 KB workgroup per CU walks the tiles
     hipStream_t s = (hipStream_t)stream;
