@@ -12,7 +12,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 # per-file extras.  attn: keep MFMA accumulators in arch VGPRs (gfx950's register file is unified) — the
 # softmax touches them with VALU every tile and the AGPR form costs ~250 v_accvgpr moves per key tile.
-EXTRA = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+         # backward: additionally no SLP vectorizer — its v_pk_* packing of the dS arithmetic costs 48 register-pair moves per tile
+         # (dK/dV kernel 4 % slower); the forward keeps it (its packed forms are written out and measured 2 % faster)
+         "attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
 
 
 def sources():

@@ -1,0 +1,102 @@
+// Shared pieces of the attention kernels (attn.hip: forward; attn_bwd.hip: delta, dQ, dK/dV).
+#pragma once
+#include <type_traits>
+#include "dcv_common.hpp"
+#include "../../include/dcv.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnArgs {
+    const bf16_t* qkv;  // [B,N,3,H,64]
+    bf16_t* o;          // [B,N,H*64]           (fwd out / bwd in)
+    const bf16_t* dO;   // [B,N,H*64]
+    float* lse;         // [B,H,N]
+    float* delta;       // [B,H,N]
+    bf16_t* dqkv;       // [B,N,3,H,64]
+    int B, N, H;
+    float scale;
+};
+
+// stage a [64 rows][64 cols] bf16 tile: 512 chunks of 16 B, 256 threads x 2
+struct Stage64 {
+    uint4 r[2];
+};
+__device__ __forceinline__ void stage_load(Stage64& s, const bf16_t* base, size_t row_stride, int row0, int nrows_valid_max, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int q = tid + 256 * i, row = q >> 3, ch = q & 7;
+        int gr = min(row0 + row, nrows_valid_max - 1);  // clamp: tail rows are masked by the caller
+        s.r[i] = *reinterpret_cast<const uint4*>(base + (size_t)gr * row_stride + ch * 8);
+    }
+}
+__device__ __forceinline__ void stage_store(const Stage64& s, char* tile, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int q = tid + 256 * i, row = q >> 3, ch = q & 7;
+        lds_write128(tile, row * 128 + ((ch ^ swz64(row)) << 4), s.r[i]);
+    }
+}
+
+// A-operand fragment from ROW reads: lane (r32,h) gets tile[row0 + r32][16*ks + 8h .. +7]
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row0, int r32, int h, int ks) {
+    int row = row0 + r32;
+    return as_bf16x8(lds_read128(tile, row * 128 + (((2 * ks + h) ^ swz64(row)) << 4)));
+}
+// A-operand fragment of the TRANSPOSED tile for k-step s of a product that sums over tile rows in the
+// accumulator-permuted order: lane (r32 = column c0 + r32 of the tile, h), element j = tile[rowbase + 16s +
+// 8(j>>2) + 4h + (j&3)][c0 + r32]
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int rowbase, int s, int c0, int lane) {
+    const int h = lane >> 5, g1 = (lane >> 4) & 1, li = lane & 15;
+    const int row = rowbase + 16 * s + 4 * h + (li >> 2);
+    const int col = c0 + 16 * g1 + 4 * (li & 3);
+    bf16x4 lo = lds_tr_read(tile, lds64_off(row, col));
+    bf16x4 hi = lds_tr_read(tile, lds64_off(row + 8, col));
+    return join4(lo, hi);
+}
+
+__device__ __forceinline__ void zero_acc(f32x16& x) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = 0.f;
+}
+
+// Per-lane LDS byte offsets computed ONCE per kernel; every fragment address in the tile loops is then
+// lane_offset + compile-time constant (buffer, tile, 32-row block, k-step), which the compiler folds into the
+// ds_read `offset:` immediate — the loops carry no address arithmetic.
+struct LaneOffs {
+    int rows[4];     // frag_rows: row r32 of a 32-row block, k-step ks      (+ 4096 per 32-row block)
+    int cols[2][2];  // frag_cols: [dt][lo|hi] for rows 4h + (li>>2) (+8)    (+ 4096 per 32-row block, + 2048 per k-step)
+};
+__device__ __forceinline__ LaneOffs lane_offs(int lane) {
+    LaneOffs o;
+    const int h = lane >> 5, r32 = lane & 31, g1 = (lane >> 4) & 1, li = lane & 15;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) o.rows[ks] = r32 * 128 + (((2 * ks + h) ^ swz64(r32)) << 4);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int row = 4 * h + (li >> 2), col = 32 * dt + 16 * g1 + 4 * (li & 3);
+        o.cols[dt][0] = lds64_off(row, col);
+        o.cols[dt][1] = lds64_off(row + 8, col);
+    }
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K/V ring: 4 stages x (8 KB K + 8 KB V), filled by LDS-DMA three tiles ahead (48 KB in flight per workgroup).
+// A register-staged single-tile prefetch left every key tile waiting ~1.5 us for its loads (measured: 3400 cycles
+// per tile for 512 cycles of MFMA).  Each wave issues 4 DMA instructions per stage: rows [16w,16w+16) of K and of V.
+constexpr int KV_STAGES = 4, KV_STAGE_BYTES = 16384;
+constexpr int FWD_WAVES = 4, FWD_QTILE = 32 * FWD_WAVES;  // query rows per workgroup: K/V re-reads scale with 1/FWD_QTILE
+constexpr int KV_DMA_PER_WAVE = 16 / FWD_WAVES;            // DMA instructions per stage per wave (8 rows x 128 B each; K: 8, V: 8)
+
+
+inline int attn_check(const void* qkv, int B, int N, int H, int hd) {
+    if (!qkv) return DCV_ERR_NULL;
+    if (B <= 0 || N <= 0 || H <= 0) return DCV_ERR_SHAPE;
+    if (hd != 64) return DCV_ERR_UNSUPPORTED;
+    if ((uintptr_t)qkv & 15) return DCV_ERR_ALIGN;
+    return DCV_OK;
+}
+
+}  // namespace

@@ -158,6 +158,19 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
         : "v"(voff), "s"(sbase), "s"(lds_wave_base)
         : "memory");
 }
+// 4-byte-per-lane form (64 consecutive floats per wave instruction)
+__device__ __forceinline__ void glds4s(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_wave_base)
+        : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
