@@ -68,6 +68,44 @@ __device__ __forceinline__ void unpack8_bf16(uint4 u, float* v) {
     v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
     v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
+// Streaming (non-temporal) 16-byte accesses for data this kernel touches exactly once — the output tile, the residual
+// and the saved pre-activation: they must not evict the A row-panel, which the other column tiles of the same XCD are
+// about to re-read, from the 4 MB L2 (PMC before: fc1 fetched its 77 MB A operand 3.3 times).
+#ifndef DCV_NT_STREAM
+#define DCV_NT_STREAM 1
+#endif
+#ifndef DCV_RESID_LD_STREAM
+#define DCV_RESID_LD_STREAM 0
+#endif
+#ifndef DCV_RESID_ST_STREAM
+#define DCV_RESID_ST_STREAM 0
+#endif
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st128_stream(void* p, uint4 v) {
+#if DCV_NT_STREAM
+    u32x4_t x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<u32x4_t*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ uint4 ld128_stream(const void* p) {
+#if DCV_NT_STREAM
+    u32x4_t x = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(x.x, x.y, x.z, x.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ void load8_f32_stream(const float* p, float* v) {
+    uint4 a = ld128_stream(p), b = ld128_stream(p + 4);
+    v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.y); v[2] = __uint_as_float(a.z); v[3] = __uint_as_float(a.w);
+    v[4] = __uint_as_float(b.x); v[5] = __uint_as_float(b.y); v[6] = __uint_as_float(b.z); v[7] = __uint_as_float(b.w);
+}
+__device__ __forceinline__ void store8_f32_stream(float* p, const float* v) {
+    st128_stream(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+    st128_stream(p + 4, make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])));
+}
 __device__ __forceinline__ void load8_f32(const float* p, float* v) {
     float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -88,9 +126,13 @@ __device__ __forceinline__ void epi_aux8(const GemmNtArgs& a, int m, int n, floa
         // residual is read from aux when given (out-of-place keeps the layer input alive for the LayerNorm backward
         // at no extra traffic), else the output is updated in place
         const float* rsd = a.aux ? (const float*)a.aux + (size_t)m * a.ldaux + n : (const float*)a.out + (size_t)m * a.ldo + n;
+#if DCV_RESID_LD_STREAM
+        load8_f32_stream(rsd, x);
+#else
         load8_f32(rsd, x);
+#endif
     } else if constexpr (EPI == DCV_EPI_GELU_BWD_BF16) {
-        unpack8_bf16(*reinterpret_cast<const uint4*>((const bf16_t*)a.aux + (size_t)m * a.ldaux + n), x);
+        unpack8_bf16(ld128_stream((const bf16_t*)a.aux + (size_t)m * a.ldaux + n), x);
     } else if constexpr (EPI == DCV_EPI_PATCH) {
         // row m = b*T + t ; token t = c*n + i  ->  channel_embed[c] + pos[1+i]
         const int b = m / a.T, t = m - b * a.T;
@@ -108,26 +150,30 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
     if constexpr (EPI == DCV_EPI_BIAS_BF16) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bz[e];
-        *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
+        st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_BIAS_GELU_BF16) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bz[e];
         const uint4 zb = pack8_bf16(v);  // pre-activation, saved for backward
-        *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = zb;
+        st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, zb);
         unpack8_bf16(zb, v);             // activation of the ROUNDED pre-activation (what backward differentiates)
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_exact(v[e]);
-        *reinterpret_cast<uint4*>((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n) = pack8_bf16(v);
+        st128_stream((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bz[e] + x[e];
+#if DCV_RESID_ST_STREAM
+        store8_f32_stream((float*)a.out + (size_t)m * a.ldo + n, v);
+#else
         store8_f32((float*)a.out + (size_t)m * a.ldo + n, v);
+#endif
     } else if constexpr (EPI == DCV_EPI_PLAIN_BF16) {
-        *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
+        st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_GELU_BWD_BF16) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gelu_grad(x[e]);
-        *reinterpret_cast<uint4*>((bf16_t*)a.out + (size_t)m * a.ldo + n) = pack8_bf16(v);
+        st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_PATCH) {
         const int b = m / a.T, t = m - b * a.T;
 #pragma unroll
