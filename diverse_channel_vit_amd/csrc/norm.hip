@@ -9,25 +9,49 @@
 
 namespace {
 
-constexpr int MAXV = 4;  // float4 per lane: D <= 64*4*4 = 1024
+#ifndef DCV_LN_NT
+#define DCV_LN_NT 1
+#endif
+#ifndef DCV_LN_FWD_ROWS
+#define DCV_LN_FWD_ROWS 1
+#endif
+#ifndef DCV_LN_NT_ST
+#define DCV_LN_NT_ST 0  // measured: non-temporal stores +1.5..2 us on both kernels (and the next GEMM re-reads these rows)
+#endif
+#if DCV_LN_NT_ST
+#define LN_STORE(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define LN_STORE(p, v) (*(p) = (v))
+#endif
+#if DCV_LN_NT
+#define LN_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define LN_LOAD(p) (*(p))
+#endif
 
-template <bool OUT_F32>
+constexpr int MAXV_MAX = 4;  // float4 per lane: D <= 64*4*4 = 1024; the kernels are instantiated for 2 (D <= 512) and 4
+
+template <bool OUT_F32, int MAXV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, void* __restrict__ u,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
                                                      float eps, long x_row_stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;  // float4 per row
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    // Measured (tools/ab_bench.py, M = 100 416, D = 384): two rows per wave and iteration (twice the bytes in flight) 45.9 us,
+    // one row 44.0-44.9 us, non-temporal loads +1 us: the kernel sits at 5.3 TB/s for other reasons than latency.
+    auto load_row = [&](int row, f32x4(&v)[MAXV]) {
         const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_row_stride);
-        float4 v[MAXV];
-        float s = 0.f;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             int c = lane + 64 * i;
-            v[i] = (c < nv) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-            s += v[i].x + v[i].y + v[i].z + v[i].w;
+            v[i] = (c < nv) ? reinterpret_cast<const f32x4*>(xr)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    auto finish_row = [&](int row, const f32x4(&v)[MAXV]) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
         const float mu = wave_sum(s) / D;
         float q = 0.f;
 #pragma unroll
@@ -51,16 +75,35 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 const float4 bb = reinterpret_cast<const float4*>(beta)[c];
                 float o0 = (v[i].x - mu) * rs * g.x + bb.x, o1 = (v[i].y - mu) * rs * g.y + bb.y;
                 float o2 = (v[i].z - mu) * rs * g.z + bb.z, o3 = (v[i].w - mu) * rs * g.w + bb.w;
-                if constexpr (OUT_F32)
-                    reinterpret_cast<float4*>((float*)u + (size_t)row * D)[c] = make_float4(o0, o1, o2, o3);
-                else
-                    reinterpret_cast<uint2*>((bf16_t*)u + (size_t)row * D)[c] = pack4_bf16(o0, o1, o2, o3);
+                if constexpr (OUT_F32) {
+                    LN_STORE(reinterpret_cast<f32x4*>((float*)u + (size_t)row * D) + c, (f32x4{o0, o1, o2, o3}));
+                } else {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const uint2 pk = pack4_bf16(o0, o1, o2, o3);
+                    LN_STORE(reinterpret_cast<u32x2*>((bf16_t*)u + (size_t)row * D) + c, (u32x2{pk.x, pk.y}));
+                }
             }
         }
+    };
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+#if DCV_LN_FWD_ROWS == 2
+    for (; row + stride < M; row += 2 * stride) {
+        f32x4 va[MAXV], vb[MAXV];
+        load_row(row, va);
+        load_row(row + stride, vb);
+        finish_row(row, va);
+        finish_row(row + stride, vb);
+    }
+#endif
+    for (; row < M; row += stride) {
+        f32x4 va[MAXV];
+        load_row(row, va);
+        finish_row(row, va);
     }
 }
 
-template <bool DU_F32>
+template <bool DU_F32, int MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dx_in, float* dx_out,
@@ -74,9 +117,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-        const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * x_row_stride);
-        const float mu = mean[row], rs = rstd[row];
+    // everything a row needs from HBM (x, du, the incoming residual gradient, its two statistics) is loaded up front, with
+    // non-temporal loads: 134 -> 124 us at M = 100 416, D = 384 (the row count per iteration made no difference)
+    struct RowIn {
+        f32x4 xv[MAXV], d[MAXV], pin[MAXV];
+        float mu, rs;
+    };
+    auto load_row = [&](int row, RowIn& r) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * x_row_stride);
+        r.mu = mean[row];
+        r.rs = rstd[row];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            int c = lane + 64 * i;
+            r.xv[i] = r.d[i] = r.pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nv) {
+                r.xv[i] = LN_LOAD(xr + c);
+                if constexpr (DU_F32) {
+                    r.d[i] = LN_LOAD(reinterpret_cast<const f32x4*>((const float*)du + (size_t)row * D) + c);
+                } else {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 raw = LN_LOAD(reinterpret_cast<const u32x2*>((const bf16_t*)du + (size_t)row * D) + c);
+                    r.d[i] = f32x4{bf16_bits_to_f32(raw.x & 0xffff), bf16_bits_to_f32(raw.x >> 16), bf16_bits_to_f32(raw.y & 0xffff),
+                                   bf16_bits_to_f32(raw.y >> 16)};
+                }
+                if (dx_in) r.pin[i] = LN_LOAD(reinterpret_cast<const f32x4*>(dx_in + (size_t)row * dx_row_stride) + c);
+            }
+        }
+    };
+    auto finish_row = [&](int row, const RowIn& in) {
+        const float mu = in.mu, rs = in.rs;
         float4 xh[MAXV], g[MAXV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -84,15 +154,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du
             int c = lane + 64 * i;
             xh[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < nv) {
-                float4 xv = xr[c];
-                float4 d;
-                if constexpr (DU_F32) {
-                    d = reinterpret_cast<const float4*>((const float*)du + (size_t)row * D)[c];
-                } else {
-                    uint2 raw = reinterpret_cast<const uint2*>((const bf16_t*)du + (size_t)row * D)[c];
-                    d = make_float4(bf16_bits_to_f32(raw.x & 0xffff), bf16_bits_to_f32(raw.x >> 16),
-                                    bf16_bits_to_f32(raw.y & 0xffff), bf16_bits_to_f32(raw.y >> 16));
-                }
+                const f32x4 xv = in.xv[i], d = in.d[i];
                 const float4 gm = reinterpret_cast<const float4*>(gamma)[c];
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 g[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
@@ -107,16 +169,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du
         for (int i = 0; i < MAXV; ++i) {
             int c = lane + 64 * i;
             if (c < nv) {
-                float4 r = make_float4(rs * (g[i].x - m1 - xh[i].x * m2), rs * (g[i].y - m1 - xh[i].y * m2),
-                                       rs * (g[i].z - m1 - xh[i].z * m2), rs * (g[i].w - m1 - xh[i].w * m2));
-                if (dx_in) {
-                    float4 p = reinterpret_cast<const float4*>(dx_in + (size_t)row * dx_row_stride)[c];
-                    r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w;
+                f32x4 r = {rs * (g[i].x - m1 - xh[i].x * m2) + in.pin[i].x, rs * (g[i].y - m1 - xh[i].y * m2) + in.pin[i].y,
+                           rs * (g[i].z - m1 - xh[i].z * m2) + in.pin[i].z, rs * (g[i].w - m1 - xh[i].w * m2) + in.pin[i].w};
+                LN_STORE(reinterpret_cast<f32x4*>(dx_out + (size_t)row * dx_row_stride) + c, r);
+                if (dx_bf16) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const uint2 pk = pack4_bf16(r.x, r.y, r.z, r.w);
+                    LN_STORE(reinterpret_cast<u32x2*>(dx_bf16 + (size_t)row * D) + c, (u32x2{pk.x, pk.y}));
                 }
-                reinterpret_cast<float4*>(dx_out + (size_t)row * dx_row_stride)[c] = r;
-                if (dx_bf16) reinterpret_cast<uint2*>(dx_bf16 + (size_t)row * D)[c] = pack4_bf16(r.x, r.y, r.z, r.w);
             }
         }
+    };
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
+    for (; row + stride < M; row += 2 * stride) {
+        RowIn ra, rb;
+        load_row(row, ra);
+        load_row(row + stride, rb);
+        finish_row(row, ra);
+        finish_row(row + stride, rb);
+    }
+    if (row < M) {
+        RowIn ra;
+        load_row(row, ra);
+        finish_row(row, ra);
     }
     // column reduction across the 4 waves, then one atomic per column per workgroup
 #pragma unroll
@@ -144,13 +220,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du
 extern "C" int dcv_ln_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, void* out, int out_is_f32,
                           float* mean, float* rstd, int M, int D, float eps, void* stream) {
     if (!x || !gamma || !beta || !out) return DCV_ERR_NULL;
-    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAXV || (x_row_stride & 3)) return DCV_ERR_SHAPE;
+    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAXV_MAX || (x_row_stride & 3)) return DCV_ERR_SHAPE;
     int grid = (M + 3) / 4;
     if (grid > 4096) grid = 4096;
-    if (out_is_f32)
-        hipLaunchKernelGGL(ln_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride);
-    else
-        hipLaunchKernelGGL(ln_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride);
+#define DCV_LN_FWD(F32, V) \
+    hipLaunchKernelGGL((ln_fwd_kernel<F32, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride)
+    if (D <= 512) {
+        if (out_is_f32) DCV_LN_FWD(true, 2);
+        else DCV_LN_FWD(false, 2);
+    } else {
+        if (out_is_f32) DCV_LN_FWD(true, 4);
+        else DCV_LN_FWD(false, 4);
+    }
+#undef DCV_LN_FWD
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
@@ -159,15 +241,20 @@ extern "C" int dcv_ln_bwd(const void* du, int du_is_f32, const float* x, long x_
                           const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
                           float* dbeta, int M, int D, void* stream) {
     if (!du || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta) return DCV_ERR_NULL;
-    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAXV || (x_row_stride & 3) || (dx_row_stride & 3)) return DCV_ERR_SHAPE;
+    if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAXV_MAX || (x_row_stride & 3) || (dx_row_stride & 3)) return DCV_ERR_SHAPE;
     int grid = (M + 3) / 4;
     if (grid > 1024) grid = 1024;
-    if (du_is_f32)
-        hipLaunchKernelGGL(ln_bwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, du, x, mean, rstd, gamma, dx_in, dx_out,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, du, x, mean, rstd, gamma, dx_in, dx_out,
-                           (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride);
+#define DCV_LN_BWD(F32, V)                                                                                                          \
+    hipLaunchKernelGGL((ln_bwd_kernel<F32, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, du, x, mean, rstd, gamma, dx_in, dx_out, \
+                       (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride)
+    if (D <= 512) {
+        if (du_is_f32) DCV_LN_BWD(true, 2);
+        else DCV_LN_BWD(false, 2);
+    } else {
+        if (du_is_f32) DCV_LN_BWD(true, 4);
+        else DCV_LN_BWD(false, 4);
+    }
+#undef DCV_LN_BWD
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

@@ -36,6 +36,14 @@ du=torch.empty(M,D,dtype=torch.bfloat16,device="cuda")
 r["gemm_du2_plain_us"]=t(lambda: hip.gemm_nt(z,W2,hip.EPI_PLAIN_BF16,du))
 r["gemm_dO_plain_us"]=t(lambda: hip.gemm_nt(A,Wp,hip.EPI_PLAIN_BF16,du))
 r["gemm_dz_gelubwd_us"]=t(lambda: hip.gemm_nt(A,W1,hip.EPI_GELU_BWD_BF16,hh,aux=z))
+xs=[torch.randn(M,D,device="cuda") for _ in range(3)]; g=torch.ones(D,device="cuda"); bb=torch.zeros(D,device="cuda"); u=torch.empty(M,D,dtype=torch.bfloat16,device="cuda"); mean=torch.empty(M,device="cuda"); rstd=torch.empty(M,device="cuda")
+dus=[torch.randn(M,D,device="cuda").to(torch.bfloat16) for _ in range(3)]; dxi=torch.randn(M,D,device="cuda"); dxo=torch.empty(M,D,device="cuda"); dxb=torch.empty(M,D,dtype=torch.bfloat16,device="cuda"); dg=torch.zeros(D,device="cuda"); db2=torch.zeros(D,device="cuda")
+it=[0]
+def lnf():
+    it[0]+=1; hip.ln_fwd(xs[it[0]%3],g,bb,u,mean,rstd,M,D,1e-6)
+def lnb():
+    it[0]+=1; hip.ln_bwd(dus[it[0]%3],xs[it[0]%3],mean,rstd,g,dxi,dxo,dxb,dg,db2,M,D)
+r["ln_fwd_us"]=t(lnf); r["ln_bwd_us"]=t(lnb)
 print(json.dumps(r))
 '''
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
