@@ -4,7 +4,10 @@
 
 namespace {
 
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
+// Row statistics for the two backward kernels, written into the workspace ws (2*B*H*N floats):
+//   ws[0 .. BHN)      = -delta,  delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]   (negated: dK/dV uses it as the initial value
+//                                                                               of the dP accumulator, so dP - delta costs nothing)
+//   ws[BHN .. 2 BHN)  = LSE * log2(e)                                          (the exp2 argument offset, no per-tile multiply)
 __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
     const int D = a.H * 64;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;  // over B*N*H
@@ -23,7 +26,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += (float)x[e] * (float)y[e];
     }
-    a.delta[((size_t)b * a.H + hh) * a.N + n] = s;
+    const size_t o = ((size_t)b * a.H + hh) * a.N + n;
+    a.delta[o] = -s;
+    a.delta[total + o] = a.lse[o] * LOG2E;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -84,13 +89,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
         dof[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(dop + 16 * ks + 8 * h));
     }
     const size_t sidx = ((size_t)b * a.H + hh) * a.N + qc;
-    const float lse2 = a.lse[sidx] * LOG2E;
-    const float dlt = a.delta[sidx];
+    const float lse2 = a.delta[(size_t)a.B * a.H * a.N + sidx];  // LSE * log2(e)
+    const float ndlt = a.delta[sidx];                          // -delta
     const float c = a.scale * LOG2E;
     // consume the plain loads here: hipcc's wait for them must not land inside the tile loop (it would drain the ring)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]), "v"(dof[ks]));
-    asm volatile("" ::"v"(lse2), "v"(dlt));
+    asm volatile("" ::"v"(lse2), "v"(ndlt));
     for (int st = 0; st < DQ_STAGES - 1; ++st)
         if (st < nt) kv_issue(st, st);
     const LaneOffs lo = lane_offs(lane);
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
                 if constexpr (decltype(MASKED)::value) {
                     if (t * 64 + 32 * kb + acc_row(r, h) >= a.N) p = 0.f;
                 }
-                s[r] = p * (dp[r] - dlt);  // dS^T (the 1/sqrt(d) factor is applied once, to dQ)
+                s[r] = p * (dp[r] + ndlt);  // dS^T (the 1/sqrt(d) factor is applied once, to dQ)
             }
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     const bf16_t* Kb = Qb + D;
     const bf16_t* Vb = Qb + 2 * D;
     const bf16_t* dOb = a.dO + (size_t)b * a.N * D + hh * 64;
-    // waves 0/2 fetch LSE rows, waves 1/3 delta rows; waves 2,3 write theirs to the scratch slot (uniform DMA count per wave)
-    const float* statb = ((wave & 1) ? a.delta : a.lse) + ((size_t)b * a.H + hh) * a.N;
+    // waves 0/2 fetch LSE*log2e rows, waves 1/3 -delta rows; waves 2,3 write theirs to the scratch slot (uniform DMA count per wave)
+    const float* statb = a.delta + ((wave & 1) ? 0 : (size_t)a.B * a.H * a.N) + ((size_t)b * a.H + hh) * a.N;  // odd: -delta, even: LSE*log2e
     const int nt = (a.N + 63) / 64;
 
     const int rowl = 16 * wave + (lane >> 3);
@@ -266,8 +271,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s, dp;
+            f32x4 l4[4];
             zero_acc(s);
-            zero_acc(dp);
+            // the dP accumulator starts at -delta of its query rows (registers 4g..4g+3 = rows 8g+4h..+3: one 16-byte read)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                l4[g] = *reinterpret_cast<const f32x4*>(sQO + sto + (32 * qb + 8 * g) * 4);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sQO + sto + 256 + (32 * qb + 8 * g) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp[4 * g + e] = d4[e];
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 s = mfma32(as_bf16x8(lds_read128(sQO, ro[ks] + qb * 4096)), kf[ks], s);
@@ -275,16 +288,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sQO + sto + (32 * qb + 8 * g) * 4);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sQO + sto + 256 + (32 * qb + 8 * g) * 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float p = __builtin_amdgcn_exp2f(s[4 * g + e] * c - l4[e] * LOG2E);
+                    float p = __builtin_amdgcn_exp2f(s[4 * g + e] * c - l4[g][e]);
                     if constexpr (decltype(MASKED)::value) {
                         if (t * 64 + 32 * qb + 8 * g + 4 * h + e >= a.N) p = 0.f;  // query row does not exist
                     }
                     s[4 * g + e] = p;
-                    dp[4 * g + e] = p * (dp[4 * g + e] - d4[e]);
+                    dp[4 * g + e] = p * dp[4 * g + e];  // dS = P * (dP - delta)
                 }
             }
 #pragma unroll
@@ -331,11 +342,12 @@ static int bwd_check(const void* qkv, const void* o, const void* dO, const float
     return DCV_OK;
 }
 
-extern "C" int dcv_attn_bwd_delta(const void* o, const void* dO, float* delta_ws, int B, int N, int H, int head_dim, void* stream) {
-    if (!o || !dO || !delta_ws) return DCV_ERR_NULL;
+extern "C" int dcv_attn_bwd_delta(const void* o, const void* dO, const float* lse, float* delta_ws, int B, int N, int H, int head_dim,
+                                  void* stream) {
+    if (!o || !dO || !lse || !delta_ws) return DCV_ERR_NULL;
     if (B <= 0 || N <= 0 || H <= 0) return DCV_ERR_SHAPE;
     if (head_dim != 64) return DCV_ERR_UNSUPPORTED;
-    AttnArgs a{nullptr, (bf16_t*)o, (const bf16_t*)dO, nullptr, delta_ws, nullptr, B, N, H, 0.f};
+    AttnArgs a{nullptr, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, delta_ws, nullptr, B, N, H, 0.f};
     const size_t total = (size_t)B * N * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
@@ -369,7 +381,7 @@ extern "C" int dcv_attn_bwd(const void* qkv, const void* o, const void* dO, cons
     int rc = bwd_check(qkv, o, dO, lse, delta_ws, B, N, H, head_dim);
     if (rc) return rc;
     if (!dqkv) return DCV_ERR_NULL;
-    if ((rc = dcv_attn_bwd_delta(o, dO, delta_ws, B, N, H, head_dim, stream))) return rc;
+    if ((rc = dcv_attn_bwd_delta(o, dO, lse, delta_ws, B, N, H, head_dim, stream))) return rc;
     if ((rc = dcv_attn_bwd_dq(qkv, dO, lse, delta_ws, dqkv, B, N, H, head_dim, scale, stream))) return rc;
     return dcv_attn_bwd_dkdv(qkv, dO, lse, delta_ws, dqkv, B, N, H, head_dim, scale, stream);
 }

@@ -596,7 +596,7 @@ class DiChaViT(nn.Module):
         du = torch.empty(M, D, dtype=bf, device=dev)
         dO = torch.empty(M, D, dtype=bf, device=dev)
         dqkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
-        delta = torch.empty(B, H, N, dtype=f32, device=dev)
+        delta = torch.empty(2, B, H, N, dtype=f32, device=dev)  # attention backward workspace: -delta, lse*log2e
         for li in range(len(fe.blocks) - 1, -1, -1):
             blk, L = fe.blocks[li], st["layers"][li]
             # MLP

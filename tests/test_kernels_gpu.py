@@ -161,7 +161,7 @@ def test_attention_fwd_bwd(hip, B, N, H):
     dO = _bf(B, N, D, seed=7)
     o_ref.backward(dO.float())
     dqkv = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
-    delta = torch.empty(B, H, N, device="cuda")
+    delta = torch.empty(2, B, H, N, device="cuda")
     hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, scale)
     assert torch.isfinite(dqkv.float()).all()
     g = qr.grad.reshape(B, N, 3, D)
@@ -288,7 +288,7 @@ def test_attention_long_sequence_base_heads(hip):
     dO = _bf(B, N, D, seed=7)
     o_ref.backward(dO.float())
     dqkv = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device="cuda")
-    delta = torch.empty(B, H, N, device="cuda")
+    delta = torch.empty(2, B, H, N, device="cuda")
     hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, scale)
     g = qr.grad.reshape(B, N, 3, D)
     d = dqkv.float().reshape(B, N, 3, D)

@@ -9,7 +9,7 @@ hip.load()
 B,N,H=64,1569,6; D=384; M=B*N
 torch.manual_seed(0)
 qkv=torch.randn(B,N,3*D,device="cuda").to(torch.bfloat16); o=torch.empty(B,N,D,dtype=torch.bfloat16,device="cuda"); lse=torch.empty(B,H,N,device="cuda")
-dO=torch.randn(B,N,D,device="cuda").to(torch.bfloat16); dqkv=torch.empty_like(qkv); delta=torch.empty(B,H,N,device="cuda")
+dO=torch.randn(B,N,D,device="cuda").to(torch.bfloat16); dqkv=torch.empty_like(qkv); delta=torch.empty(2,B,H,N,device="cuda")
 A=torch.randn(M,D,device="cuda").to(torch.bfloat16); W=torch.randn(3*D,D,device="cuda").to(torch.bfloat16)*0.05; bias=torch.zeros(3*D,device="cuda"); out=torch.empty(M,3*D,dtype=torch.bfloat16,device="cuda")
 W1=torch.randn(4*D,D,device="cuda").to(torch.bfloat16)*0.05; b1=torch.zeros(4*D,device="cuda"); z=torch.empty(M,4*D,dtype=torch.bfloat16,device="cuda"); hh=torch.empty_like(z)
 dW=torch.zeros(3*D,D,device="cuda"); db=torch.zeros(3*D,device="cuda")

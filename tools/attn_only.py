@@ -6,7 +6,7 @@ hip.load()
 B, N, H, D = 64, 1569, 6, 384
 torch.manual_seed(0)
 qkv = torch.randn(B, N, 3 * D, device="cuda").to(torch.bfloat16); o = torch.empty(B, N, D, dtype=torch.bfloat16, device="cuda"); lse = torch.empty(B, H, N, device="cuda")
-dO = torch.randn(B, N, D, device="cuda").to(torch.bfloat16); dqkv = torch.empty_like(qkv); delta = torch.empty(B, H, N, device="cuda")
+dO = torch.randn(B, N, D, device="cuda").to(torch.bfloat16); dqkv = torch.empty_like(qkv); delta = torch.empty(2, B, H, N, device="cuda")
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     hip.attn_fwd(qkv, o, lse, B, N, H, 64, 0.125)
     hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, 0.125)

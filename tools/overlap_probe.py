@@ -7,7 +7,7 @@ B, N, H = 64, 1569, 6; D = 384; M = B * N
 torch.manual_seed(0)
 bf = torch.bfloat16
 qkv = torch.randn(B, N, 3 * D, device="cuda").to(bf); o = torch.randn(B, N, D, device="cuda").to(bf); lse = torch.zeros(B, H, N, device="cuda")
-dO = torch.randn(B, N, D, device="cuda").to(bf); dqkv = torch.empty_like(qkv); delta = torch.empty(B, H, N, device="cuda")
+dO = torch.randn(B, N, D, device="cuda").to(bf); dqkv = torch.empty_like(qkv); delta = torch.empty(2, B, H, N, device="cuda")
 hip.attn_fwd(qkv, o, lse, B, N, H, 64, 0.125)
 A = torch.randn(M, D, device="cuda").to(bf); Y3 = torch.randn(M, 3 * D, device="cuda").to(bf); Z = torch.randn(M, 4 * D, device="cuda").to(bf)
 dWq = torch.zeros(3 * D, D, device="cuda"); dWp = torch.zeros(D, D, device="cuda"); dW1 = torch.zeros(4 * D, D, device="cuda"); dW2 = torch.zeros(D, 4 * D, device="cuda")
