@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd2_kernel(AttnArgs a) {
 
     const int q = qt * FWD_QTILE + wave * 32 + r32;
     const int qc = min(q, a.N - 1);
+    const bool active = qt * FWD_QTILE + wave * 32 < a.N;  // N = 1569: the 13th query tile has 33 rows, 3 of its 4 waves none
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Qb + (size_t)qc * rs + 16 * ks + 8 * h));
@@ -195,9 +196,11 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd2_kernel(AttnArgs a) {
 #if !(DCV_ABL2 & 2)
         if (t + 3 < nt) kv_issue2(t + 3);
 #endif
-        if constexpr (nx == 1) scores(No{}, nxt, t + 1);
-        if constexpr (nx == 2) scores(Yes{}, nxt, t + 1);
-        softmax_pv(cur, t);
+        if (active) {  // wave-uniform: a wave whose 32 query rows all lie beyond N only keeps the K/V ring going
+            if constexpr (nx == 1) scores(No{}, nxt, t + 1);
+            if constexpr (nx == 2) scores(Yes{}, nxt, t + 1);
+            softmax_pv(cur, t);
+        }
     };
     using N0 = std::integral_constant<int, 0>;
     using N1 = std::integral_constant<int, 1>;
@@ -219,8 +222,10 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void attn_fwd2_kernel(AttnArgs a) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     f32x16 sa[2], sb[2];
-    if (nfull == 0) scores(Yes{}, sa, 0);
-    else scores(No{}, sa, 0);
+    if (active) {
+        if (nfull == 0) scores(Yes{}, sa, 0);
+        else scores(No{}, sa, 0);
+    }
     int t = 0;
     for (; t + 2 < nfull; t += 2) {  // steps whose next tile is a full one, two at a time (register ping-pong)
         step(N1{}, sa, sb, t);

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
 
     const int q = qt * 128 + wave * 32 + r32;
     const int qc = min(q, a.N - 1);
+    const bool active = qt * 128 + wave * 32 < a.N;  // a wave without a single valid query row only keeps the ring going
     bf16x8 qf[4], dof[4];
     const bf16_t* dop = a.dO + ((size_t)b * a.N + qc) * D + hh * 64;
 #pragma unroll
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
         if (t + 2 < nt) kv_issue(t + 2, slot == 0 ? 2 : slot - 1);  // (t + 2) % 3
+        if (!active) return;
         const int so = slot * KV_STAGE_BYTES;
         int ro[4], co[2][2];
 #pragma unroll
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
 
     const int key = kt * 128 + wave * 32 + r32;  // this lane's key
     const int kc = min(key, a.N - 1);
+    const bool active = kt * 128 + wave * 32 < a.N;  // a wave without a single valid key only keeps the ring going
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
         if (t + 3 < nt) issue(t + 3, (slot + 3) & 3);
+        if (!active) return;
         const int so = slot * DKV_STAGE_BYTES;
         int ro[4], co[2][2];
 #pragma unroll
