@@ -89,9 +89,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
         qf[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Qb + (size_t)qc * rs + 16 * ks + 8 * h));
         dof[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(dop + 16 * ks + 8 * h));
     }
+    // Row statistics of this lane's query, computed here and written to the workspace for the dK/dV kernel (which runs
+    // after this one): -delta = -sum_d dO*O and LSE*log2(e).  (attn_delta_kernel computes the same pair stand-alone.)
     const size_t sidx = ((size_t)b * a.H + hh) * a.N + qc;
-    const float lse2 = a.delta[(size_t)a.B * a.H * a.N + sidx];  // LSE * log2(e)
-    const float ndlt = a.delta[sidx];                          // -delta
+    const float lse2 = a.lse[sidx] * LOG2E;
+    float ndlt = 0.f;
+    {
+        const bf16_t* orow = a.o + ((size_t)b * a.N + qc) * D + hh * 64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 of = as_bf16x8(*reinterpret_cast<const uint4*>(orow + 16 * ks + 8 * h));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ndlt -= (float)of[e] * (float)dof[ks][e];
+        }
+        ndlt += __shfl_xor(ndlt, 32, 64);  // the two lane halves hold the two 8-element groups of every 16
+        if (h == 0 && q < a.N) {
+            a.delta[sidx] = ndlt;
+            a.delta[(size_t)a.B * a.H * a.N + sidx] = lse2;
+        }
+    }
     const float c = a.scale * LOG2E;
     // consume the plain loads here: hipcc's wait for them must not land inside the tile loop (it would drain the ring)
 #pragma unroll
@@ -358,12 +374,12 @@ extern "C" int dcv_attn_bwd_delta(const void* o, const void* dO, const float* ls
     return DCV_OK;
 }
 
-extern "C" int dcv_attn_bwd_dq(const void* qkv, const void* dO, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
+extern "C" int dcv_attn_bwd_dq(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int H,
                                int head_dim, float scale, void* stream) {
-    int rc = bwd_check(qkv, dO, dO, lse, (float*)delta, B, N, H, head_dim);
+    int rc = bwd_check(qkv, o, dO, lse, ws, B, N, H, head_dim);
     if (rc) return rc;
     if (!dqkv) return DCV_ERR_NULL;
-    AttnArgs a{(const bf16_t*)qkv, nullptr, (const bf16_t*)dO, (float*)lse, (float*)delta, (bf16_t*)dqkv, B, N, H, scale};
+    AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, ws, (bf16_t*)dqkv, B, N, H, scale};
     hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(B * H * ((N + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
@@ -385,8 +401,7 @@ extern "C" int dcv_attn_bwd(const void* qkv, const void* o, const void* dO, cons
     int rc = bwd_check(qkv, o, dO, lse, delta_ws, B, N, H, head_dim);
     if (rc) return rc;
     if (!dqkv) return DCV_ERR_NULL;
-    if ((rc = dcv_attn_bwd_delta(o, dO, lse, delta_ws, B, N, H, head_dim, stream))) return rc;
-    if ((rc = dcv_attn_bwd_dq(qkv, dO, lse, delta_ws, dqkv, B, N, H, head_dim, scale, stream))) return rc;
+    if ((rc = dcv_attn_bwd_dq(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, head_dim, scale, stream))) return rc;  // also fills the workspace
     return dcv_attn_bwd_dkdv(qkv, dO, lse, delta_ws, dqkv, B, N, H, head_dim, scale, stream);
 }
 

@@ -25,7 +25,7 @@ _SIGS = {
     "dcv_attn_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_delta": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
-    "dcv_attn_bwd_dq": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd_dq": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_dkdv": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_im2col_bf16": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "dcv_patch_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
@@ -166,9 +166,8 @@ def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale):
     lib = load()
     if delta_ws.numel() < 2 * B * H * N or delta_ws.dtype != torch.float32:
         raise ValueError("attention backward workspace: 2*B*H*N float32 (-delta, then lse*log2e)")
-    _check(lib.dcv_attn_bwd_delta(_p(o), _p(dO), _p(lse), _p(delta_ws), B, N, H, hd, _stream()), "dcv_attn_bwd_delta")
-    with _timed("attn_bwd_dq"):
-        rc = lib.dcv_attn_bwd_dq(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, H, hd, scale, _stream())
+    with _timed("attn_bwd_dq"):  # also writes the row statistics into the workspace
+        rc = lib.dcv_attn_bwd_dq(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dq")
     with _timed("attn_bwd_dkdv"):
         rc = lib.dcv_attn_bwd_dkdv(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, H, hd, scale, _stream())

@@ -59,15 +59,16 @@ int dcv_ln_bwd(const void* du, int du_is_f32, const float* x, long x_row_stride,
 /* softmax(q k^T * scale) v for packed qkv [B,N,3,H,64] bf16 -> o [B,N,H*64] bf16, lse [B,H,N] f32.
  * Replaces Attention.forward's q@k^T / softmax / @v (vit.py:123-141); the [B,H,N,N] matrix is never stored. */
 int dcv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale, void* stream);
-/* dqkv [B,N,3,H,64] bf16 from (qkv, o, dO, lse).  ws: f32 workspace of 2*B*H*N floats, filled by the first launch:
- *   ws[0 .. BHN) = -delta, delta[b,h,q] = sum_d dO*O;  ws[BHN .. 2 BHN) = lse * log2(e). */
+/* dqkv [B,N,3,H,64] bf16 from (qkv, o, dO, lse).  ws: f32 workspace of 2*B*H*N floats holding the row statistics
+ *   ws[0 .. BHN) = -delta, delta[b,h,q] = sum_d dO*O;  ws[BHN .. 2 BHN) = lse * log2(e).
+ * Two launches: dQ (which also writes ws), then dK/dV (which reads it). */
 int dcv_attn_bwd(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N,
                  int H, int head_dim, float scale, void* stream);
-/* the three launches dcv_attn_bwd makes, individually (profiling / stream placement): the row statistics into ws (layout
- * above) ; dQ slot of dqkv ; dK and dV slots of dqkv.  `ws` of the last two is what the first one wrote; their `lse`
- * argument is kept for symmetry and not read. */
+/* the launches individually (profiling / stream placement).  dcv_attn_bwd_dq fills the dQ slot of dqkv AND ws;
+ * dcv_attn_bwd_dkdv fills the dK and dV slots and needs ws filled (by dcv_attn_bwd_dq or by dcv_attn_bwd_delta, which
+ * computes only the statistics); its `lse` argument is kept for symmetry and not read. */
 int dcv_attn_bwd_delta(const void* o, const void* dO, const float* lse, float* ws, int B, int N, int H, int head_dim, void* stream);
-int dcv_attn_bwd_dq(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int H,
+int dcv_attn_bwd_dq(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int H,
                     int head_dim, float scale, void* stream);
 int dcv_attn_bwd_dkdv(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int H,
                       int head_dim, float scale, void* stream);
