@@ -143,7 +143,8 @@ def _attn_ref(qkv, B, N, H, scale):
     return o, torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 64, 1), (2, 289, 6), (1, 1569, 6), (3, 130, 2), (8, 50, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 3), (1, 64, 1), (2, 289, 6), (1, 1569, 6), (3, 130, 2), (8, 50, 1),
+                                   (1, 17, 2), (2, 33, 1), (1, 128, 3), (1, 129, 1), (1, 192, 2), (2, 257, 1)])
 def test_attention_fwd_bwd(hip, B, N, H):
     D = H * 64
     scale = 64 ** -0.5
