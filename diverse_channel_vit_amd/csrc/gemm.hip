@@ -397,6 +397,163 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_nt384: the same product on a 256 x 384 output tile, for N % 384 == 0 (every Linear of the encoder: 384, 1152, 1536).
+// Why: the 256 x 128 kernel is bound by operand delivery into LDS (34-37 GB/s per CU sustained, whatever the epilogue), so
+// its main-loop time scales with operand BYTES: (256+128)*2 B per 256*128*2 FLOP and k = 85 FLOP/B.  256 x 384 moves
+// (256+384)*2 B per 256*384*2 FLOP = 154 FLOP/B, 1.8x fewer bytes per FLOP.  Cost: 192 accumulator registers per lane
+// (8 waves as 4 (M) x 2 (N), each 64 x 192 = 2 x 6 MFMA tiles; they live in AGPRs, the loop needs ~40 arch VGPRs) and the
+// whole LDS: two 80 KB stages.  With two buffers the next stage is issued after the barrier that retires the previous
+// one, one k-iteration (48 MFMAs per wave) ahead.  Tile walk, slab epilogue and fused ops as in gemm_nt_kernel.
+constexpr int N3_BM = 256, N3_BN = 384, N3_BK = 64;
+constexpr int N3_A_BYTES = N3_BM * N3_BK * 2, N3_W_BYTES = N3_BN * N3_BK * 2, N3_STAGE_BYTES = N3_A_BYTES + N3_W_BYTES;  // 80 KB
+constexpr int N3_SMEM = 2 * N3_STAGE_BYTES;                                                                              // 160 KB
+constexpr int N3_DMA = 10;  // per wave and stage: A rows [32w, 32w+32) = 4 pieces, W rows [48w, 48w+48) = 6 pieces
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[N3_SMEM];
+    constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
+    constexpr bool HAS_AUX = (EPI == DCV_EPI_BIAS_RESID_F32) || (EPI == DCV_EPI_GELU_BWD_BF16);
+    static_assert(EPI != DCV_EPI_PATCH, "the tokeniser epilogue stays on the 256 x 128 kernel");
+    constexpr int S = 3 * nt_stores_per_wave<EPI>();  // stores one wave issues in a full tile's epilogue
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, r32 = lane & 31;
+    const int tiles_n = a.N / N3_BN;
+    const int tiles_m = (a.M + N3_BM - 1) / N3_BM;
+    const int total = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int pos = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned dmaA = 32 * wave * 128, dmaW = N3_A_BYTES + 48 * wave * 128;  // wave-uniform byte offsets in a stage
+    const int nk = a.K / N3_BK;
+    const int sw = swz64(r32);
+    const int rowA = (wm * 64 + r32) * 128, rowW = N3_A_BYTES + (wn * 192 + r32) * 128;
+    constexpr int EP_LD = 68;
+    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+
+    // DMA sources: a scalar tile base + per-lane byte offsets that do not depend on the tile (the partial last M tile
+    // recomputes the A offsets with its rows clamped to M-1)
+    unsigned voffA[4], voffW[6];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 32 * wave + 8 * q + (lane >> 3);
+        voffA[q] = (unsigned)(((size_t)row * a.lda + (((lane & 7) ^ swz64(row)) * 8)) * 2);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int row = 48 * wave + 8 * q + (lane >> 3);
+        voffW[q] = (unsigned)(((size_t)row * a.ldw + (((lane & 7) ^ swz64(row)) * 8)) * 2);
+    }
+    auto issue = [&](int m0, int n0, int kt, unsigned stage_base) {
+        const bf16_t* ab = a.A + (size_t)m0 * a.lda + kt * N3_BK;  // scalar
+        const bf16_t* wb = a.W + (size_t)n0 * a.ldw + kt * N3_BK;
+        if (m0 + N3_BM <= a.M) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glds16s(ab, voffA[q], stage_base + dmaA + q * 1024);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = 32 * wave + 8 * q + (lane >> 3);
+                const int rc = min(m0 + row, a.M - 1) - m0;
+                glds16s(ab, (unsigned)(((size_t)rc * a.lda + (((lane & 7) ^ swz64(row)) * 8)) * 2), stage_base + dmaA + q * 1024);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) glds16s(wb, voffW[q], stage_base + dmaW + q * 1024);
+    };
+
+    int L = pos;
+    if (L >= total) return;
+    int m0 = (L / tiles_n) * N3_BM, n0 = (L % tiles_n) * N3_BN;
+    int g = 0;  // global stage counter: stage g lives in buffer g & 1
+    issue(m0, n0, 0, smem_base);
+    bool stores_behind = false;
+
+    for (;;) {
+        f32x16 acc[2][6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            // stage kt landed once only younger operations are outstanding: for kt == 0 the previous tile's S epilogue
+            // stores (issued after this tile's first stage); afterwards nothing of ours is younger than the stage
+            if (kt == 0 && stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done with buffer (g+1)&1 (reads / slabs)
+            if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
+            const char* st = smem + (g & 1) * N3_STAGE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int co = ((2 * ks + h) ^ sw) << 4;
+                bf16x8 af[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[i] = as_bf16x8(lds_read128(st, rowA + i * 32 * 128 + co));
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const bf16x8 wf = as_bf16x8(lds_read128(st, rowW + j * 32 * 128 + co));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][j] = mfma32(af[i], wf, acc[i][j]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: buffer (g-1)&1 now holds the slabs
+
+        // ---- epilogue, overlapped with the first stage of the next tile (into the other buffer) ----
+        const int Ln = L + G;
+        const bool has_next = Ln < total;
+        const int m0n = has_next ? (Ln / tiles_n) * N3_BM : 0, n0n = has_next ? (Ln % tiles_n) * N3_BN : 0;
+        if (has_next) issue(m0n, n0n, 0, smem_base + (g & 1) * N3_STAGE_BYTES);
+        float* ep = reinterpret_cast<float*>(smem + ((g + 1) & 1) * N3_STAGE_BYTES) + wave * 16 * EP_LD;
+        const bool full = (m0 + N3_BM <= a.M);
+        const int mbase = m0 + wm * 64;
+#pragma unroll
+        for (int cg = 0; cg < 3; ++cg) {  // 64-column groups of the wave's 192 columns
+            const int nn = n0 + wn * 192 + cg * 64 + ecol;
+            float bz[8];
+            if constexpr (HAS_BIAS) load8_f32(a.bias + nn, bz);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {  // quarter = 16 rows: block i = qt>>1, accumulator registers 8*(qt&1) .. +7
+                const int i = qt >> 1, rb = 8 * (qt & 1);
+                // auxiliary rows: both passes up front where registers allow, one at a time for the GELU-backward epilogue
+                // (its gradient arithmetic needs the room: with both it spilled and ran 14 % slower than the 256 x 128 kernel)
+                constexpr bool AUX_EARLY = HAS_AUX && (EPI != DCV_EPI_GELU_BWD_BF16);
+                float x[AUX_EARLY ? 2 : 1][8];
+                if constexpr (AUX_EARLY) {
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps) epi_aux8<EPI>(a, min(mbase + (qt * 2 + ps) * 8 + erow, a.M - 1), nn, x[ps]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + r32] = acc[i][2 * cg + j][rb + r];
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int row = ps * 8 + erow;
+                    const int mm = mbase + (qt * 2 + ps) * 8 + erow;
+                    if constexpr (HAS_AUX && !AUX_EARLY) epi_aux8<EPI>(a, min(mm, a.M - 1), nn, x[0]);
+                    float v[8];
+                    load8_f32(ep + row * EP_LD + ecol, v);
+                    if (mm < a.M) epi_store8<EPI>(a, mm, nn, v, x[AUX_EARLY ? ps : 0], bz);
+                }
+            }
+        }
+        if (!has_next) break;
+        stores_behind = full;
+        m0 = m0n;
+        n0 = n0n;
+        L = Ln;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct GemmTnArgs {
     const bf16_t* Y;
     int ldy;
@@ -724,6 +881,41 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
     if (grid > grid_cap) grid = grid_cap;  // persistent: one 144 KB workgroup per CU walks the tiles
     hipStream_t s = (hipStream_t)stream;
+    // 256 x 384 tiles where they pay (measured, M = 100 416, against the 256 x 128 kernel): N = 1152 K = 384: 121 -> 107 us;
+    // N = 1536 K = 384 + GELU: 238 -> 218; N = 384 K = 1536: 192 -> 184 (+residual), 154 -> 138 (plain); but N = 384 K = 384:
+    // 96 -> 101 (393 tiles on 256 CUs: two rounds for 1.5 rounds of work), and the GELU-backward epilogue (N = 1536) 255 -> 263.  DCV_NT384 = 0 / 1 forces never / always.
+    const char* n3env = getenv("DCV_NT384");  // read per call: tests switch it
+    const bool legal384 = (N % N3_BN) == 0 && epilogue != DCV_EPI_PATCH && M >= 4096;
+    const bool use384 = legal384 && (n3env && n3env[0] ? n3env[0] == '1' : ((N >= 1152 || K >= 1152) && epilogue != DCV_EPI_GELU_BWD_BF16));
+    if (use384) {
+        int g3 = ((M + N3_BM - 1) / N3_BM) * (N / N3_BN);
+        if (g3 > grid_cap) g3 = grid_cap;
+        switch (epilogue) {
+            case DCV_EPI_BIAS_BF16:
+                if (!bias) return DCV_ERR_NULL;
+                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_BIAS_BF16>, dim3(g3), dim3(512), 0, s, a);
+                break;
+            case DCV_EPI_BIAS_GELU_BF16:
+                if (!bias || !out2) return DCV_ERR_NULL;
+                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_BIAS_GELU_BF16>, dim3(g3), dim3(512), 0, s, a);
+                break;
+            case DCV_EPI_BIAS_RESID_F32:
+                if (!bias) return DCV_ERR_NULL;
+                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_BIAS_RESID_F32>, dim3(g3), dim3(512), 0, s, a);
+                break;
+            case DCV_EPI_PLAIN_BF16:
+                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_PLAIN_BF16>, dim3(g3), dim3(512), 0, s, a);
+                break;
+            case DCV_EPI_GELU_BWD_BF16:
+                if (!aux) return DCV_ERR_NULL;
+                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_GELU_BWD_BF16>, dim3(g3), dim3(512), 0, s, a);
+                break;
+            default:
+                return DCV_ERR_UNSUPPORTED;
+        }
+        DCV_LAUNCH_CHECK();
+        return DCV_OK;
+    }
     switch (epilogue) {
         case DCV_EPI_BIAS_BF16:
             if (!bias) return DCV_ERR_NULL;

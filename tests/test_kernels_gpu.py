@@ -72,6 +72,14 @@ def test_gemm_nt_epilogues(hip, M, N, K):
     _close(out, ref * zf.grad, 1e-2, 2e-2, "gelu_bwd")
 
 
+@pytest.mark.parametrize("M,N,K", [(4100, 1152, 384), (4352, 384, 1536), (4608, 1536, 384), (5000, 384, 64)])
+def test_gemm_nt_384_wide_tiles(hip, M, N, K, monkeypatch):
+    """The 256 x 384 tile kernel (gemm_nt384, used for N % 384 == 0 where it pays) on every epilogue it carries, forced on
+    with DCV_NT384=1: full tiles, a partial last M tile, one and several k-stages, 1 / 3 / 4 column tiles."""
+    monkeypatch.setenv("DCV_NT384", "1")
+    test_gemm_nt_epilogues(hip, M, N, K)
+
+
 def test_gemm_nt_patch_epilogue(hip):
     B, C, n, D, PP = 3, 5, 16, 384, 64
     T = C * n
