@@ -83,10 +83,10 @@ __device__ __forceinline__ LaneOffs lane_offs(int lane) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K/V ring: 4 stages x (8 KB K + 8 KB V), filled by LDS-DMA three tiles ahead (48 KB in flight per workgroup).
+// Tile rings: stages of (8 KB K + 8 KB V) or (8 KB Q + 8 KB dO), filled by LDS-DMA two or three tiles ahead.
 // A register-staged single-tile prefetch left every key tile waiting ~1.5 us for its loads (measured: 3400 cycles
-// per tile for 512 cycles of MFMA).  Each wave issues 4 DMA instructions per stage: rows [16w,16w+16) of K and of V.
-constexpr int KV_STAGES = 4, KV_STAGE_BYTES = 16384;
+// per tile for 512 cycles of MFMA).  Each wave issues 4 DMA instructions per stage: rows [16w,16w+16) of either tile.
+constexpr int KV_STAGE_BYTES = 16384;  // one ring stage: a 64-row K (or Q) tile + a 64-row V (or dO) tile
 constexpr int FWD_WAVES = 4, FWD_QTILE = 32 * FWD_WAVES;  // query rows per workgroup: K/V re-reads scale with 1/FWD_QTILE
 constexpr int KV_DMA_PER_WAVE = 16 / FWD_WAVES;            // DMA instructions per stage per wave (8 rows x 128 B each; K: 8, V: 8)
 
