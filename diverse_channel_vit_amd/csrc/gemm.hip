@@ -38,7 +38,7 @@ struct GemmNtArgs {
 };
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7: far below the bf16 rounding of the outputs), sharing
-// e = exp(-z^2/2) with the Gaussian pdf of GELU'.
+// e = exp(-z^2/2) with the Gaussian pdf of GELU':  GELU(z) = z * cdf,  GELU'(z) = cdf + z * e / sqrt(2 pi).
 __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& e) {
     const float x = fabsf(z) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
@@ -47,17 +47,6 @@ __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& e) {
     const float erf_abs = 1.0f - poly * e;
     cdf = 0.5f * (1.0f + copysignf(erf_abs, z));
 }
-__device__ __forceinline__ float gelu_exact(float z) {
-    float cdf, e;
-    gelu_parts(z, cdf, e);
-    return z * cdf;
-}
-__device__ __forceinline__ float gelu_grad(float z) {
-    float cdf, e;
-    gelu_parts(z, cdf, e);
-    return cdf + z * 0.39894228040143268f * e;
-}
-
 __device__ __forceinline__ uint4 pack8_bf16(const float* v) {
     uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -152,13 +141,18 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
         for (int e = 0; e < 8; ++e) v[e] += bz[e];
         st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_BIAS_GELU_BF16) {
+        // out = GELU'(z), out2 = GELU(z), z = acc + bias in fp32: the backward then only multiplies (the first version saved z
+        // and recomputed the erf / exp in the backward epilogue, ~45 % of that kernel's time); cdf and exp(-z^2/2) are shared
+        float gp[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bz[e];
-        const uint4 zb = pack8_bf16(v);  // pre-activation, saved for backward
-        st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, zb);
-        unpack8_bf16(zb, v);             // activation of the ROUNDED pre-activation (what backward differentiates)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_exact(v[e]);
+        for (int e = 0; e < 8; ++e) {
+            const float z = v[e] + bz[e];
+            float cdf, ex;
+            gelu_parts(z, cdf, ex);
+            v[e] = z * cdf;
+            gp[e] = cdf + z * 0.39894228040143268f * ex;
+        }
+        st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(gp));
         st128_stream((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
 #pragma unroll
@@ -172,7 +166,7 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
         st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_GELU_BWD_BF16) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= gelu_grad(x[e]);
+        for (int e = 0; e < 8; ++e) v[e] *= x[e];  // x = GELU'(z) as the forward epilogue saved it
         st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_PATCH) {
         const int b = m / a.T, t = m - b * a.T;
@@ -521,9 +515,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {  // quarter = 16 rows: block i = qt>>1, accumulator registers 8*(qt&1) .. +7
                 const int i = qt >> 1, rb = 8 * (qt & 1);
-                // auxiliary rows: both passes up front where registers allow, one at a time for the GELU-backward epilogue
-                // (its gradient arithmetic needs the room: with both it spilled and ran 14 % slower than the 256 x 128 kernel)
-                constexpr bool AUX_EARLY = HAS_AUX && (EPI != DCV_EPI_GELU_BWD_BF16);
+                constexpr bool AUX_EARLY = HAS_AUX;  // the auxiliary rows of both passes are loaded before the slab round trip
                 float x[AUX_EARLY ? 2 : 1][8];
                 if constexpr (AUX_EARLY) {
 #pragma unroll
@@ -883,7 +875,7 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     hipStream_t s = (hipStream_t)stream;
     // 256 x 384 tiles where they pay (measured, M = 100 416, against the 256 x 128 kernel): N = 1152 K = 384: 121 -> 107 us;
     // N = 1536 K = 384 + GELU: 238 -> 218; N = 384 K = 1536: 192 -> 184 (+residual), 154 -> 138 (plain); but N = 384 K = 384:
-    // 96 -> 101 (393 tiles on 256 CUs: two rounds for 1.5 rounds of work), and the GELU-backward epilogue (N = 1536) 255 -> 263.  DCV_NT384 = 0 / 1 forces never / always.
+    // 96 -> 101 (393 tiles on 256 CUs: two rounds for 1.5 rounds of work), and the GELU-backward epilogue (N = 1536, HBM-heavy: 616 MB in + out) 212 -> 220.  DCV_NT384 = 0 / 1 forces never / always.
     const char* n3env = getenv("DCV_NT384");  // read per call: tests switch it
     const bool legal384 = (N % N3_BN) == 0 && epilogue != DCV_EPI_PATCH && M >= 4096;
     const bool use384 = legal384 && (n3env && n3env[0] ? n3env[0] == '1' : ((N >= 1152 || K >= 1152) && epilogue != DCV_EPI_GELU_BWD_BF16));

@@ -550,7 +550,7 @@ class DiChaViT(nn.Module):
             u2 = torch.empty(M, D, dtype=bf, device=dev)
             mean2, rstd2 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
             hip.ln_fwd(xmid, blk.norm2.weight, blk.norm2.bias, u2, mean2, rstd2, M, D, LN_EPS)
-            z = torch.empty(M, 4 * D, dtype=bf, device=dev)
+            z = torch.empty(M, 4 * D, dtype=bf, device=dev)  # GELU'(pre-activation), saved for the backward
             hact = torch.empty(M, 4 * D, dtype=bf, device=dev)
             hip.gemm_nt(u2, self._bf(blk.mlp.fc1.weight), hip.EPI_BIAS_GELU_BF16, z, bias=blk.mlp.fc1.bias, out2=hact)
             xout = torch.empty(M, D, dtype=f32, device=dev) if save else xmid

@@ -26,10 +26,10 @@ extern "C" {
 
 /* dcv_gemm_nt epilogues */
 #define DCV_EPI_BIAS_BF16 0      /* out bf16 = acc + bias                         (attn.qkv, vit.py:123)            */
-#define DCV_EPI_BIAS_GELU_BF16 1 /* out bf16 = z = acc + bias ; out2 bf16 = GELU_erf(z) (mlp.fc1 + act, vit.py:77-78) */
+#define DCV_EPI_BIAS_GELU_BF16 1 /* z = acc + bias (fp32): out bf16 = GELU_erf'(z), out2 bf16 = GELU_erf(z) (mlp.fc1 + act, vit.py:77-78) */
 #define DCV_EPI_BIAS_RESID_F32 2 /* out f32 = (aux f32 ? aux : out) + acc + bias (attn.proj / mlp.fc2 + residual, vit.py:142,397-398) */
 #define DCV_EPI_PLAIN_BF16 3     /* out bf16 = acc                                 (input gradients)                */
-#define DCV_EPI_GELU_BWD_BF16 4  /* out bf16 = acc * GELU'(aux bf16)               (grad through act, vit.py:78)    */
+#define DCV_EPI_GELU_BWD_BF16 4  /* out bf16 = acc * aux bf16, aux = the saved GELU'(z)  (grad through act, vit.py:78)    */
 #define DCV_EPI_PATCH 5          /* tokens: out f32[b,1+t,:] = acc + bias + aux[c(t),:] + aux2[1+i(t),:] ;
                                     out2 f32[b*T+t,:] = acc + bias (optional)       (dichavit.py:377,409-415,565)   */
 

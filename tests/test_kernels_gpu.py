@@ -50,11 +50,14 @@ def test_gemm_nt_epilogues(hip, M, N, K):
     # plain
     hip.gemm_nt(A, W, hip.EPI_PLAIN_BF16, out)
     _close(out, ref, 1e-2, 2e-2, "plain_bf16")
-    # bias + gelu (z and h)
+    # bias + gelu: out = GELU'(z), out2 = GELU(z), z = acc + bias
     h = torch.empty_like(out)
     hip.gemm_nt(A, W, hip.EPI_BIAS_GELU_BF16, out, bias=bias, out2=h)
-    _close(out, ref + bias, 1e-2, 2e-2, "gelu z")
-    _close(h, torch.nn.functional.gelu(out.float()), 1e-2, 1e-2, "gelu h")
+    zr = (ref + bias).requires_grad_(True)
+    hr = torch.nn.functional.gelu(zr)
+    hr.sum().backward()
+    _close(h, hr.detach(), 1e-2, 2e-2, "gelu h")
+    _close(out, zr.grad, 1e-2, 2e-2, "gelu'")
     # residual f32 in place
     x = _f(M, N, seed=4)
     x0 = x.clone()
@@ -64,12 +67,10 @@ def test_gemm_nt_epilogues(hip, M, N, K):
     hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, y, bias=bias, aux=x0)  # out-of-place residual
     _close(y, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32 out-of-place")
     assert torch.equal(y, x)
-    # gelu backward epilogue
-    z = _bf(M, N, seed=5)
-    hip.gemm_nt(A, W, hip.EPI_GELU_BWD_BF16, out, aux=z)
-    zf = z.float().requires_grad_(True)
-    torch.nn.functional.gelu(zf).sum().backward()
-    _close(out, ref * zf.grad, 1e-2, 2e-2, "gelu_bwd")
+    # gelu backward epilogue: acc * saved GELU'
+    gp = _bf(M, N, seed=5)
+    hip.gemm_nt(A, W, hip.EPI_GELU_BWD_BF16, out, aux=gp)
+    _close(out, ref * gp.float(), 1e-2, 2e-2, "gelu_bwd")
 
 
 @pytest.mark.parametrize("M,N,K", [(4100, 1152, 384), (4352, 384, 1536), (4608, 1536, 384), (5000, 384, 64)])

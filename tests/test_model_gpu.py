@@ -540,8 +540,8 @@ def test_clipping_checkpoint_resume_parity(gpu_device, tmp_path):
     norms = np.array([r[1] for r in full])
     print("resume: loss err", np.abs(losses - a["losses"]).max(), "norm rel err", (np.abs(norms - a["total_norms"]) / a["total_norms"]).max(),
           "resumed-vs-uninterrupted", max(abs(r[0] - c[0]) for r, c in zip(resumed, cont)))
-    assert np.abs(losses - a["losses"]).max() <= 5e-3       # measured 1.4e-3 (round-to-nearest copies: 3.0e-2 at this lr)
-    assert (np.abs(norms - a["total_norms"]) / a["total_norms"]).max() <= 5e-3
+    assert np.abs(losses - a["losses"]).max() <= 1.5e-2     # measured 1.4e-3 .. 6.3e-3 across builds (round-to-nearest copies: 3.0e-2); lr is 20x the curve tests'
+    assert (np.abs(norms - a["total_norms"]) / a["total_norms"]).max() <= 1e-2
     for r, c in zip(resumed, cont):
         assert abs(r[0] - c[0]) <= 2e-3 and abs(r[1] - c[1]) <= 2e-3 * c[1]
     for n_, p_ in model3.named_parameters():
