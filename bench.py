@@ -283,7 +283,15 @@ def main():
             "config": {"workload": f"DiChaViT-{args.arch} {C}ch {args.img}x{args.img} P16 {args.classes} classes, train step "
                                    f"(fwd + CE + ortho/proxy regularisers + bwd + fused AdamW), bs {args.batch}/GPU, N={N} tokens",
                        "global_batch": args.batch * world, "seq_len": N, "parallelism": f"dp{world}",
-                       "step_roofline_frac": round(imgs / world * TRAIN_GFLOP_PER_IMG * 1e9 / PEAK_BF16, 4) if (args.arch, C, args.img) == ("small", 8, 224) else None,
+                       # the reference's 336.94 GFLOP/img include the rows of the LAST block that never reach the output (everything
+                       # after its attention on the non-CLS tokens, and all but the CLS query of that attention): 3 * (18 N D^2 +
+                       # 4 N^2 D) (N-1)/N = 23.82 GFLOP/img that this path does not execute.  The fraction is quoted on EXECUTED FLOPs.
+                       "step_roofline_frac": round(imgs / world * (TRAIN_GFLOP_PER_IMG - (23.82 if model.cls_only_tail else 0.0)) * 1e9 / PEAK_BF16, 4)
+                       if (args.arch, C, args.img) == ("small", 8, 224) else None,
+                       "executed_gflop_per_img": round(TRAIN_GFLOP_PER_IMG - (23.82 if model.cls_only_tail else 0.0), 2) if (args.arch, C, args.img) == ("small", 8, 224) else None,
+                       "dead_rows": ("last block: token-wise ops after the attention on the CLS rows only, attention for the CLS query only "
+                                     "(the encoder returns norm(x)[:, 0]; same outputs and gradients, DCV_CLS_TAIL=0 computes every row)"
+                                     if model.cls_only_tail else "none skipped"),
                        "final_loss": round(final_loss, 5), "input": ("pinned host memory -> HBM every step (copy stream, double-buffered)" if args.h2d else "resident in HBM"), "host_syncs_per_step": 0,
                        "launch": "hip-graph replay of the captured step" if use_graph else "eager",
                        **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)",

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char sKV[ST * KV_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nqt = (a.N + 127) / 128;
+    const int nqt = (a.Nq + 127) / 128;
     const int BH = a.B * a.H;
     int bh, qt;
     if ((BH & 7) == 0) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
 
     const int q = qt * 128 + wave * 32 + r32;
     const int qc = min(q, a.N - 1);
-    const bool active = qt * 128 + wave * 32 < a.N;
+    const bool active = qt * 128 + wave * 32 < a.Nq;
     bf16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Qb + (size_t)qc * rs + 16 * ks + 8 * h));
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
 
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
-    if (q < a.N) {
+    if (q < a.Nq) {
         bf16_t* op = a.o + ((size_t)b * a.N + q) * D + hh * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -176,14 +176,19 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
 
 }  // namespace
 
-extern "C" int dcv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale, void* stream) {
+extern "C" int dcv_attn_fwd_rows(const void* qkv, void* o, float* lse, int B, int N, int Nq, int H, int head_dim, float scale,
+                                 void* stream) {
     int rc = attn_check(qkv, B, N, H, head_dim);
     if (rc) return rc;
     if (!o || !lse) return DCV_ERR_NULL;
-    AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, nullptr, lse, nullptr, nullptr, B, N, H, scale};
-    const int grid = B * H * ((N + FWD_QTILE - 1) / FWD_QTILE);
+    if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
+    AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, nullptr, lse, nullptr, nullptr, B, N, H, scale, Nq};
+    const int grid = B * H * ((Nq + FWD_QTILE - 1) / FWD_QTILE);
     hipLaunchKernelGGL(attn_fwd3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
 
+extern "C" int dcv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale, void* stream) {
+    return dcv_attn_fwd_rows(qkv, o, lse, B, N, N, H, head_dim, scale, stream);
+}

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char sKV[DQ_STAGES * KV_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nqt = (a.N + 127) / 128;
+    const int nqt = (a.N + 127) / 128;  // all query tiles: those beyond Nq only clear their dQ rows (dqkv is fully defined)
     const int BH = a.B * a.H;
     int bh, qt;
     if ((BH & 7) == 0) {
@@ -81,7 +81,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
 
     const int q = qt * 128 + wave * 32 + r32;
     const int qc = min(q, a.N - 1);
-    const bool active = qt * 128 + wave * 32 < a.N;  // a wave without a single valid query row only keeps the ring going
+    const bool active = qt * 128 + wave * 32 < a.Nq;  // a wave without a single valid query row only keeps the ring going
+    if (qt * 128 >= a.Nq) {  // whole tile beyond the processed query rows (workgroup-uniform): dQ = 0, nothing else
+        if (q < a.N) {
+            bf16_t* dst = a.dqkv + ((size_t)b * a.N + q) * rs + hh * 64;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + 8 * i + 4 * h) = make_uint2(0u, 0u);
+        }
+        return;
+    }
     bf16x8 qf[4], dof[4];
     const bf16_t* dop = a.dO + ((size_t)b * a.N + qc) * D + hh * 64;
 #pragma unroll
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
             for (int e = 0; e < 8; ++e) ndlt -= (float)of[e] * (float)dof[ks][e];
         }
         ndlt += __shfl_xor(ndlt, 32, 64);  // the two lane halves hold the two 8-element groups of every 16
-        if (h == 0 && q < a.N) {
+        if (h == 0 && q < a.Nq) {
             a.delta[sidx] = ndlt;
             a.delta[(size_t)a.B * a.H * a.N + sidx] = lse2;
         }
@@ -174,7 +182,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     }
     if (nfull < nt) tile(Yes{}, nfull, slot);
 
-    if (q < a.N) {
+    if (q >= a.Nq && q < a.N) {  // rows of this tile beyond the processed ones: dQ = 0
+        bf16_t* dst = a.dqkv + ((size_t)b * a.N + q) * rs + hh * 64;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint2*>(dst + 8 * i + 4 * h) = make_uint2(0u, 0u);
+    }
+    if (q < a.Nq) {
         bf16_t* dst = a.dqkv + ((size_t)b * a.N + q) * rs + hh * 64;  // slot 0 = dQ
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     const bf16_t* dOb = a.dO + (size_t)b * a.N * D + hh * 64;
     // waves 0/2 fetch LSE*log2e rows, waves 1/3 -delta rows; waves 2,3 write theirs to the scratch slot (uniform DMA count per wave)
     const float* statb = a.delta + ((wave & 1) ? 0 : (size_t)a.B * a.H * a.N) + ((size_t)b * a.H + hh) * a.N;  // odd: -delta, even: LSE*log2e
-    const int nt = (a.N + 63) / 64;
+    const int nt = (a.Nq + 63) / 64;
 
     const int rowl = 16 * wave + (lane >> 3);
     const int lc8[2] = {((lane & 7) ^ swz64(rowl)) * 8, ((lane & 7) ^ swz64(rowl + 8)) * 8};
@@ -234,13 +247,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         const bf16_t* ot = dOb + (size_t)t * 64 * D;
         const float* st = statb + t * 64;
         unsigned q0 = vq0, q1 = vq1, o0 = vo0, o1 = vo1, s0 = vs;
-        if (t * 64 + 64 > a.N) {  // partial tile: clamp rows >= N to N-1 (their P is zeroed in the masked tile body)
-            const int r0 = min(t * 64 + rowl, a.N - 1) - t * 64, r1 = min(t * 64 + rowl + 8, a.N - 1) - t * 64;
+        if (t * 64 + 64 > a.Nq) {  // partial tile: clamp query rows >= Nq to Nq-1 (valid data; their P is zeroed in the masked tile body)
+            const int r0 = min(t * 64 + rowl, a.Nq - 1) - t * 64, r1 = min(t * 64 + rowl + 8, a.Nq - 1) - t * 64;
             q0 = (unsigned)(((size_t)r0 * rs + lc8[0]) * 2);
             q1 = (unsigned)(((size_t)r1 * rs + lc8[1]) * 2);
             o0 = (unsigned)(((size_t)r0 * D + lc8[0]) * 2);
             o1 = (unsigned)(((size_t)r1 * D + lc8[1]) * 2);
-            s0 = (unsigned)(min(t * 64 + lane, a.N - 1) - t * 64) * 4;
+            s0 = (unsigned)(min(t * 64 + lane, a.Nq - 1) - t * 64) * 4;
         }
         glds16s(qt, q0, sb);
         glds16s(ot, o0, sb + 8192);
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     float p = __builtin_amdgcn_exp2f(s[4 * g + e] * c - l4[g][e]);
                     if constexpr (decltype(MASKED)::value) {
-                        if (t * 64 + 32 * qb + 8 * g + 4 * h + e >= a.N) p = 0.f;  // query row does not exist
+                        if (t * 64 + 32 * qb + 8 * g + 4 * h + e >= a.Nq) p = 0.f;  // query row does not exist
                     }
                     s[4 * g + e] = p;
                     dp[4 * g + e] = p * dp[4 * g + e];  // dS = P * (dP - delta)
@@ -333,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     };
     using No = std::integral_constant<bool, false>;
     using Yes = std::integral_constant<bool, true>;
-    const int nfull = a.N / 64;
+    const int nfull = a.Nq / 64;
     for (int t = 0; t < nfull; ++t) tile(No{}, t, t & 3);
     if (nfull < nt) tile(Yes{}, nfull, nfull & 3);
 
@@ -363,45 +376,59 @@ static int bwd_check(const void* qkv, const void* o, const void* dO, const float
 }
 
 extern "C" int dcv_attn_bwd_delta(const void* o, const void* dO, const float* lse, float* delta_ws, int B, int N, int H, int head_dim,
-                                  void* stream) {
+                                  void* stream) {  // statistics of ALL query rows
     if (!o || !dO || !lse || !delta_ws) return DCV_ERR_NULL;
     if (B <= 0 || N <= 0 || H <= 0) return DCV_ERR_SHAPE;
     if (head_dim != 64) return DCV_ERR_UNSUPPORTED;
-    AttnArgs a{nullptr, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, delta_ws, nullptr, B, N, H, 0.f};
+    AttnArgs a{nullptr, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, delta_ws, nullptr, B, N, H, 0.f, N};
     const size_t total = (size_t)B * N * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
 
-extern "C" int dcv_attn_bwd_dq(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int H,
-                               int head_dim, float scale, void* stream) {
+extern "C" int dcv_attn_bwd_dq_rows(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N,
+                                    int Nq, int H, int head_dim, float scale, void* stream) {
     int rc = bwd_check(qkv, o, dO, lse, ws, B, N, H, head_dim);
     if (rc) return rc;
     if (!dqkv) return DCV_ERR_NULL;
-    AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, ws, (bf16_t*)dqkv, B, N, H, scale};
+    if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
+    AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
     hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(B * H * ((N + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
 
-extern "C" int dcv_attn_bwd_dkdv(const void* qkv, const void* dO, const float* lse, const float* delta, void* dqkv, int B, int N, int H,
-                                 int head_dim, float scale, void* stream) {
-    int rc = bwd_check(qkv, dO, dO, lse, (float*)delta, B, N, H, head_dim);
+extern "C" int dcv_attn_bwd_dkdv_rows(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
+                                      int H, int head_dim, float scale, void* stream) {
+    int rc = bwd_check(qkv, dO, dO, lse, (float*)ws, B, N, H, head_dim);
     if (rc) return rc;
     if (!dqkv) return DCV_ERR_NULL;
-    AttnArgs a{(const bf16_t*)qkv, nullptr, (const bf16_t*)dO, (float*)lse, (float*)delta, (bf16_t*)dqkv, B, N, H, scale};
+    if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
+    AttnArgs a{(const bf16_t*)qkv, nullptr, (const bf16_t*)dO, (float*)lse, (float*)ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
     hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, dim3(B * H * ((N + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
 
-extern "C" int dcv_attn_bwd(const void* qkv, const void* o, const void* dO, const float* lse, float* delta_ws, void* dqkv, int B, int N,
-                            int H, int head_dim, float scale, void* stream) {
-    int rc = bwd_check(qkv, o, dO, lse, delta_ws, B, N, H, head_dim);
+extern "C" int dcv_attn_bwd_rows(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int Nq,
+                                 int H, int head_dim, float scale, void* stream) {
+    int rc = dcv_attn_bwd_dq_rows(qkv, o, dO, lse, ws, dqkv, B, N, Nq, H, head_dim, scale, stream);  // also fills the workspace
     if (rc) return rc;
-    if (!dqkv) return DCV_ERR_NULL;
-    if ((rc = dcv_attn_bwd_dq(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, head_dim, scale, stream))) return rc;  // also fills the workspace
-    return dcv_attn_bwd_dkdv(qkv, dO, lse, delta_ws, dqkv, B, N, H, head_dim, scale, stream);
+    return dcv_attn_bwd_dkdv_rows(qkv, dO, lse, ws, dqkv, B, N, Nq, H, head_dim, scale, stream);
 }
 
+extern "C" int dcv_attn_bwd_dq(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int H,
+                               int head_dim, float scale, void* stream) {
+    return dcv_attn_bwd_dq_rows(qkv, o, dO, lse, ws, dqkv, B, N, N, H, head_dim, scale, stream);
+}
+
+extern "C" int dcv_attn_bwd_dkdv(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int H,
+                                 int head_dim, float scale, void* stream) {
+    return dcv_attn_bwd_dkdv_rows(qkv, dO, lse, ws, dqkv, B, N, N, H, head_dim, scale, stream);
+}
+
+extern "C" int dcv_attn_bwd(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int H,
+                            int head_dim, float scale, void* stream) {
+    return dcv_attn_bwd_rows(qkv, o, dO, lse, ws, dqkv, B, N, N, H, head_dim, scale, stream);
+}

@@ -17,6 +17,7 @@ struct AttnArgs {
     bf16_t* dqkv;       // [B,N,3,H,64]
     int B, N, H;
     float scale;
+    int Nq;  // query rows [0, Nq) of every (batch, head) are processed (Nq = N: all; Nq = 1: the CLS row of the last block)
 };
 
 // stage a [64 rows][64 cols] bf16 tile: 512 chunks of 16 B, 256 threads x 2

@@ -258,6 +258,8 @@ class DiChaViT(nn.Module):
         # master every step), round-to-nearest otherwise.  DCV_WEIGHT_ROUNDING=nearest turns it off.
         self.stochastic_weight_rounding = os.environ.get("DCV_WEIGHT_ROUNDING", "stochastic") != "nearest"
         self._sr_seed = None  # device int32 word, bumped after every stochastically rounded refresh
+        # last block on the CLS rows only (exact: the encoder output is norm(x)[:, 0]); DCV_CLS_TAIL=0 computes every row
+        self.cls_only_tail = os.environ.get("DCV_CLS_TAIL", "1") != "0"
 
     # ---------------------------------------------------------------------------------------
     # arena management
@@ -535,8 +537,10 @@ class DiChaViT(nn.Module):
         scale = 64 ** -0.5
         layers = []
         xcur = xs.view(M, D)
-        for blk in fe.blocks:
+        final_stride = N * D
+        for bi, blk in enumerate(fe.blocks):
             L = {}
+            tail = self.cls_only_tail and bi == len(fe.blocks) - 1
             u1 = torch.empty(M, D, dtype=bf, device=dev)
             mean1, rstd1 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
             hip.ln_fwd(xcur, blk.norm1.weight, blk.norm1.bias, u1, mean1, rstd1, M, D, LN_EPS)
@@ -544,29 +548,45 @@ class DiChaViT(nn.Module):
             hip.gemm_nt(u1, self._bf(blk.attn.qkv.weight), hip.EPI_BIAS_BF16, qkv, bias=blk.attn.qkv.bias)
             o = torch.empty(M, D, dtype=bf, device=dev)
             lse = torch.empty(B, H, N, dtype=f32, device=dev)
-            hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale)
-            xmid = torch.empty(M, D, dtype=f32, device=dev) if save else xcur
-            hip.gemm_nt(o, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=xcur)
-            u2 = torch.empty(M, D, dtype=bf, device=dev)
-            mean2, rstd2 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
-            hip.ln_fwd(xmid, blk.norm2.weight, blk.norm2.bias, u2, mean2, rstd2, M, D, LN_EPS)
-            z = torch.empty(M, 4 * D, dtype=bf, device=dev)  # GELU'(pre-activation), saved for the backward
-            hact = torch.empty(M, 4 * D, dtype=bf, device=dev)
+            if tail:
+                # The encoder's output is read at the CLS row only (norm(x)[:, 0], dichavit.py:651-652), so in the LAST block
+                # every token-wise op after the attention needs the CLS rows alone, and the attention only the CLS query
+                # (keys and values still come from all tokens).  Same values and gradients as the reference, which computes
+                # — and then discards — the other rows.
+                hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale, nq=1)
+                o_c = o.view(B, N, D)[:, 0].contiguous()
+                x_c = xcur.view(B, N, D)[:, 0].contiguous()
+                xmid = torch.empty(B, D, dtype=f32, device=dev)
+                hip.gemm_nt(o_c, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=x_c)
+                R = B  # rows the rest of this block works on
+            else:
+                hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale)
+                o_c = None
+                xmid = torch.empty(M, D, dtype=f32, device=dev) if save else xcur
+                hip.gemm_nt(o, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=xcur)
+                R = M
+            u2 = torch.empty(R, D, dtype=bf, device=dev)
+            mean2, rstd2 = torch.empty(R, dtype=f32, device=dev), torch.empty(R, dtype=f32, device=dev)
+            hip.ln_fwd(xmid, blk.norm2.weight, blk.norm2.bias, u2, mean2, rstd2, R, D, LN_EPS)
+            z = torch.empty(R, 4 * D, dtype=bf, device=dev)  # GELU'(pre-activation), saved for the backward
+            hact = torch.empty(R, 4 * D, dtype=bf, device=dev)
             hip.gemm_nt(u2, self._bf(blk.mlp.fc1.weight), hip.EPI_BIAS_GELU_BF16, z, bias=blk.mlp.fc1.bias, out2=hact)
-            xout = torch.empty(M, D, dtype=f32, device=dev) if save else xmid
+            xout = torch.empty(R, D, dtype=f32, device=dev) if (save or tail) else xmid
             hip.gemm_nt(hact, self._bf(blk.mlp.fc2.weight), hip.EPI_BIAS_RESID_F32, xout, bias=blk.mlp.fc2.bias, aux=xmid)
             if save:
                 L.update(x_in=xcur, u1=u1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x_mid=xmid, u2=u2, mean2=mean2,
-                         rstd2=rstd2, z=z, h=hact)
+                         rstd2=rstd2, z=z, h=hact, tail=tail, o_c=o_c)
                 layers.append(L)
             xcur = xout
+            if tail:
+                final_stride = D  # the last block handed over compact CLS rows
         # --- final LayerNorm on the CLS rows only (dichavit.py:651-652) ---
         feat = torch.empty(B, D, dtype=f32, device=dev)
         meanf, rstdf = torch.empty(B, dtype=f32, device=dev), torch.empty(B, dtype=f32, device=dev)
-        hip.ln_fwd(xcur, fe.norm.weight, fe.norm.bias, feat, meanf, rstdf, B, D, LN_EPS, x_row_stride=N * D)
+        hip.ln_fwd(xcur, fe.norm.weight, fe.norm.bias, feat, meanf, rstdf, B, D, LN_EPS, x_row_stride=final_stride)
         st.update(feat=feat, stats=stats)
         if save:
-            st.update(layers=layers, x_final=xcur, meanf=meanf, rstdf=rstdf, want_ortho=want_ortho)
+            st.update(layers=layers, x_final=xcur, final_stride=final_stride, meanf=meanf, rstdf=rstdf, want_ortho=want_ortho)
         return st
 
     def _gview(self, ga, p):
@@ -584,11 +604,13 @@ class DiChaViT(nn.Module):
         g = lambda p: self._gview(ga, p)  # noqa: E731
         dp = self._dp
         # --- final LayerNorm (CLS rows) ---
-        dx = torch.zeros(M, D, dtype=f32, device=dev)
+        fs = st["final_stride"]
+        compact = fs == D  # the last block ran on the CLS rows only: its gradients are [B, D] until its attention
+        dx = torch.zeros(B if compact else M, D, dtype=f32, device=dev)
         hip.ln_bwd(dfeat, st["x_final"], st["meanf"], st["rstdf"], fe.norm.weight, None, dx, None, g(fe.norm.weight), g(fe.norm.bias),
-                   B, D, x_row_stride=N * D, dx_row_stride=N * D)
-        dxb = torch.empty(M, D, dtype=bf, device=dev)
-        hip.cast_bf16(dx, dxb, M * D)
+                   B, D, x_row_stride=fs, dx_row_stride=fs)
+        dxb = torch.empty_like(dx, dtype=bf)
+        hip.cast_bf16(dx, dxb, dx.numel())
         if dp is not None:
             dp.grad_ready(ga, *self._range_of([fe.norm.weight, fe.norm.bias]))
         scale = 64 ** -0.5
@@ -599,16 +621,30 @@ class DiChaViT(nn.Module):
         delta = torch.empty(2, B, H, N, dtype=f32, device=dev)  # attention backward workspace: -delta, lse*log2e
         for li in range(len(fe.blocks) - 1, -1, -1):
             blk, L = fe.blocks[li], st["layers"][li]
+            tail = L["tail"]
+            R = B if tail else M
+            dz_, du_ = (dz[:R], du[:R]) if tail else (dz, du)
             # MLP
-            hip.gemm_nt(dxb, self._bf(blk.mlp.fc2.weight, True), hip.EPI_GELU_BWD_BF16, dz, aux=L["z"])
+            hip.gemm_nt(dxb, self._bf(blk.mlp.fc2.weight, True), hip.EPI_GELU_BWD_BF16, dz_, aux=L["z"])
             hip.gemm_tn_acc(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias))
-            hip.gemm_nt(dz, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du)
-            hip.gemm_tn_acc(dz, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias))
-            hip.ln_bwd(du, L["x_mid"], L["mean2"], L["rstd2"], blk.norm2.weight, dx, dx, dxb, g(blk.norm2.weight), g(blk.norm2.bias), M, D)
+            hip.gemm_nt(dz_, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du_)
+            hip.gemm_tn_acc(dz_, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias))
+            hip.ln_bwd(du_, L["x_mid"], L["mean2"], L["rstd2"], blk.norm2.weight, dx, dx, dxb, g(blk.norm2.weight), g(blk.norm2.bias), R, D)
             # attention
-            hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO)
-            hip.gemm_tn_acc(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias))
-            hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
+            if tail:
+                dO_c = du[B:2 * B]  # scratch rows of the same buffer
+                hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO_c)
+                hip.gemm_tn_acc(dxb, L["o_c"], g(blk.attn.proj.weight), g(blk.attn.proj.bias))
+                dO.view(B, N, D)[:, 0].copy_(dO_c)  # only the CLS rows of dO are read (nq = 1)
+                hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale, nq=1)
+                dx_c = dx
+                dx = torch.zeros(M, D, dtype=f32, device=dev)  # the residual gradient reaches the block input at the CLS rows only
+                dx.view(B, N, D)[:, 0].copy_(dx_c)
+                dxb = torch.empty(M, D, dtype=bf, device=dev)
+            else:
+                hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO)
+                hip.gemm_tn_acc(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias))
+                hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
             hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du)
             hip.gemm_tn_acc(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias))
             hip.ln_bwd(du, L["x_in"], L["mean1"], L["rstd1"], blk.norm1.weight, dx, dx, dxb, g(blk.norm1.weight), g(blk.norm1.bias), M, D)

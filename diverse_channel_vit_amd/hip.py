@@ -27,6 +27,10 @@ _SIGS = {
     "dcv_attn_bwd_delta": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_attn_bwd_dq": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_dkdv": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_fwd_rows": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd_rows": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd_dq_rows": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd_dkdv_rows": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_im2col_bf16": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "dcv_patch_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_gather_tokens": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
@@ -155,22 +159,23 @@ def ln_bwd(du, x, mean, rstd, gamma, dx_in, dx_out, dx_bf16, dgamma, dbeta, M, D
     _check(rc, "dcv_ln_bwd")
 
 
-def attn_fwd(qkv, o, lse, B, N, H, hd, scale):
-    _req(qkv, torch.bfloat16, "qkv")
+def attn_fwd(qkv, o, lse, B, N, H, hd, scale, nq=None):
+    """nq: only the query rows [0, nq) of every (batch, head) are processed (default: all N)."""
     with _timed("attn_fwd"):
-        rc = load().dcv_attn_fwd(_p(qkv), _p(o), _p(lse), B, N, H, hd, scale, _stream())
+        rc = load().dcv_attn_fwd_rows(_p(qkv), _p(o), _p(lse), B, N, N if nq is None else nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_fwd")
 
 
-def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale):
+def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None):
     lib = load()
+    nq = N if nq is None else nq
     if delta_ws.numel() < 2 * B * H * N or delta_ws.dtype != torch.float32:
         raise ValueError("attention backward workspace: 2*B*H*N float32 (-delta, then lse*log2e)")
     with _timed("attn_bwd_dq"):  # also writes the row statistics into the workspace
-        rc = lib.dcv_attn_bwd_dq(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, H, hd, scale, _stream())
+        rc = lib.dcv_attn_bwd_dq_rows(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dq")
     with _timed("attn_bwd_dkdv"):
-        rc = lib.dcv_attn_bwd_dkdv(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, H, hd, scale, _stream())
+        rc = lib.dcv_attn_bwd_dkdv_rows(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dkdv")
 
 

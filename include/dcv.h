@@ -72,6 +72,17 @@ int dcv_attn_bwd_dq(const void* qkv, const void* o, const void* dO, const float*
                     int head_dim, float scale, void* stream);
 int dcv_attn_bwd_dkdv(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int H,
                       int head_dim, float scale, void* stream);
+/* Query-row-restricted forms: only the query rows [0, Nq) of every (batch, head) are processed (1 <= Nq <= N); keys and
+ * values are always all N rows.  Used for the LAST encoder block, whose output is read at the CLS row only
+ * (ChannelVisionTransformer.forward returns norm(x)[:, 0], dichavit.py:651-652): Nq = 1.  Forward writes o / lse rows < Nq
+ * only; backward reads dO rows < Nq only, writes dQ = 0 for the rows >= Nq and dK, dV of all keys. */
+int dcv_attn_fwd_rows(const void* qkv, void* o, float* lse, int B, int N, int Nq, int H, int head_dim, float scale, void* stream);
+int dcv_attn_bwd_rows(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int Nq,
+                      int H, int head_dim, float scale, void* stream);
+int dcv_attn_bwd_dq_rows(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N,
+                         int Nq, int H, int head_dim, float scale, void* stream);
+int dcv_attn_bwd_dkdv_rows(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
+                           int H, int head_dim, float scale, void* stream);
 
 /* x [B,Ct,H,W] f32 (x_is_u8 == 0: normalised images, the reference's batch format) or u8 (raw pixels), ch_idx int32[C]
  * (device) -> bf16 [B*C*(H/P)*(W/P), P*P] patch rows (dichavit.py:134/210,377).  scale/shift f32[C] (nullable, indexed by

@@ -350,3 +350,33 @@ def test_stochastic_cast_bit_exact_and_unbiased(gpu_device):
     rtn_err = np.abs(s.to(torch.bfloat16).float().cpu().numpy() - src)
     # standard error of the SR mean ~ ulp/(2*sqrt(3*64)) ~ ulp/28; round-to-nearest's error is ~ulp/4 on average and does not shrink
     assert mean_err.mean() < 0.35 * rtn_err.mean()
+
+
+@pytest.mark.parametrize("B,N,H,Nq", [(2, 197, 3, 1), (1, 1569, 6, 1), (3, 130, 2, 5), (2, 289, 1, 130), (1, 64, 2, 64)])
+def test_attention_query_row_subset(hip, B, N, H, Nq):
+    """dcv_attn_*_rows: only the query rows [0, Nq) are processed (the last block needs the CLS row only); keys / values are all N
+    rows.  Forward rows < Nq and the backward of a loss that reads only those rows must equal the full computation."""
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = _bf(B, N, 3 * D, scale=1.2, seed=N + Nq)
+    o = torch.full((B, N, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lse = torch.full((B, H, N), float("nan"), device="cuda")
+    hip.attn_fwd(qkv, o, lse, B, N, H, 64, scale, nq=Nq)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, B, N, H, scale)
+    _close(o[:, :Nq], o_ref[:, :Nq], 2e-2, 2e-2, "attn O rows")
+    _close(lse[:, :, :Nq], lse_ref[:, :, :Nq], 1e-4, 2e-3, "attn LSE rows")
+    dO = torch.full((B, N, D), float("nan"), dtype=torch.bfloat16, device="cuda")  # rows >= Nq must never be read
+    dO[:, :Nq] = _bf(B, Nq, D, seed=9)
+    (o_ref[:, :Nq] * dO[:, :Nq].float()).sum().backward()
+    dqkv = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ws = torch.empty(2, B, H, N, device="cuda")
+    hip.attn_bwd(qkv, o, dO, lse, ws, dqkv, B, N, H, 64, scale, nq=Nq)
+    assert torch.isfinite(dqkv.float()).all()
+    g = qr.grad.reshape(B, N, 3, D)
+    d = dqkv.float().reshape(B, N, 3, D)
+    assert (d[:, Nq:, 0] == 0).all()
+    for i, nm in enumerate(["dQ", "dK", "dV"]):
+        ref = g[:, :, i]
+        tol = 3e-2 * ref.abs().max().item()
+        _close(d[:, :, i], ref, 3e-2, tol, nm)

@@ -548,7 +548,7 @@ def test_clipping_checkpoint_resume_parity(gpu_device, tmp_path):
         if not n_.startswith("adaptive_interface"):
             ref = float(a["final_norm/" + n_])
             # six sign-like Adam steps of lr 1e-3: a gradient element whose sign flips under bf16 noise moves by 2 lr
-            assert abs(p_.detach().double().norm().item() - ref) <= 5e-3 * ref + 1e-6, n_
+            assert abs(p_.detach().double().norm().item() - ref) <= 1e-2 * ref + 1e-6, n_
 
 
 def test_clip_grad_norm_matches_torch(gpu_device):
