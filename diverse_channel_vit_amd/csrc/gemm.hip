@@ -35,6 +35,7 @@ struct GemmNtArgs {
     int ldaux;
     const float* aux2;
     int T, n;
+    unsigned* queue;  // dynamic tile queue of this launch (9 words: next index of each XCD's range, finished workgroups) or null
 };
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7: far below the bf16 rounding of the outputs), sharing
@@ -205,6 +206,29 @@ __device__ constexpr int nt_stores_per_wave() {
     return (EPI == DCV_EPI_BIAS_GELU_BF16 || EPI == DCV_EPI_BIAS_RESID_F32) ? 16 : 8;
 }
 
+// ---- dynamic tile queue (both persistent NT kernels) -------------------------------------------------------------------
+// queue[0..7]: next index inside each XCD's contiguous tile range; queue[8]: workgroups that have retired.  See gemm_nt384.
+__device__ __forceinline__ int ntq_base(int total, int x) { return (int)((long long)total * x / 8); }
+__device__ int ntq_draw(unsigned* queue, int total) {  // one thread per workgroup
+    const int home = blockIdx.x & 7;
+    for (int y = 0; y < 8; ++y) {
+        const int xx = (home + y) & 7;
+        const int base = ntq_base(total, xx), len = ntq_base(total, xx + 1) - base;
+        if (len <= 0) continue;
+        const unsigned i = atomicAdd(&queue[xx], 1u);
+        if (i < (unsigned)len) return base + (int)i;
+    }
+    return -1;
+}
+__device__ __forceinline__ void ntq_retire(unsigned* queue, int G) {  // one thread per workgroup, once
+    __threadfence();
+    if (atomicAdd(&queue[8], 1u) == (unsigned)G - 1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) queue[i] = 0u;
+    }
+}
+constexpr int NTQ_WORD = 36864;  // byte offset of the posted tile index inside a ring buffer (the epilogue slabs end at 34816)
+
 struct NtTile {
     const bf16_t* gA[4];
     const bf16_t* gW[2];
@@ -268,8 +292,32 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     constexpr int EP_LD = 68;  // floats per slab row (272 B: 16-byte aligned, rows shifted by 4 banks)
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
 
-    int L = pos;
-    if (L >= total) return;
+    // tile order: static (round k, workgroup w -> k*G + pos(w)) or drawn from the launch's queue (a.queue; gemm_nt384 explains why)
+    const bool dyn = a.queue != nullptr;
+    int L, Lnext;
+    if (dyn) {
+        int* w = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const int t0 = ntq_draw(a.queue, total);
+            w[0] = t0;
+            w[1] = t0 >= 0 ? ntq_draw(a.queue, total) : -1;
+        }
+        __syncthreads();
+        L = __builtin_amdgcn_readfirstlane(w[0]);
+        Lnext = __builtin_amdgcn_readfirstlane(w[1]);
+        __syncthreads();
+    } else {
+        L = pos < total ? pos : -1;
+        Lnext = (L >= 0 && L + G < total) ? L + G : -1;
+    }
+    if (L < 0) {
+        if (dyn && tid == 0) ntq_retire(a.queue, G);
+        return;
+    }
+    bool posted = false;
+    unsigned drawn = 0;
+    const int qhome = blockIdx.x & 7;
+    const int qbase = ntq_base(total, qhome), qlen = ntq_base(total, qhome + 1) - qbase;
     NtTile cur, nxt;
     nt_tile_setup(a, L, tiles_n, wave, lane, cur);
     int g = 0;  // global stage counter of this workgroup: stage g lives in ring buffer g % 3
@@ -310,7 +358,15 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();  // everyone's stage g landed; everyone is done with buffer (g-1)%3 (reads and slabs)
+            if (kt == 0 && posted) {  // the tile index posted in the last epilogue's slab buffer, before the DMA below reuses it
+                Lnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(smem + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES + NTQ_WORD));
+                posted = false;
+            }
             if (kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+            // the tile after next: thread 0 fires the atomic on its XCD's range here, a whole main loop before the result is looked
+            // at (at the start of the epilogue, where nothing of ours is in flight).  Fired in the epilogue instead, hipcc's wait
+            // for it drained the prefetched stages and the store tail on every tile: +20 % on the short K = 384, N = 384 product.
+            if (kt == 0 && dyn && Lnext >= 0 && tid == 0) drawn = atomicAdd(&a.queue[qhome], 1u);
             const char* st = smem + (g % NT_STAGES) * NT_STAGE_BYTES;
 #if DCV_GABL != 2
 #pragma unroll
@@ -334,8 +390,18 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: its buffer (g-1)%3 now holds the slabs
 
         // ---- epilogue of `cur`, overlapped with the first two stages of the next tile ----
-        const int Ln = L + G;
-        const bool has_next = Ln < total;
+        const int Ln = Lnext;
+        const bool has_next = Ln >= 0;
+        if (dyn) {
+            if (has_next) {
+                if (tid == 0)
+                    *reinterpret_cast<volatile int*>(smem + ((g + NT_STAGES - 1) % NT_STAGES) * NT_STAGE_BYTES + NTQ_WORD) =
+                        (drawn < (unsigned)qlen) ? qbase + (int)drawn : ntq_draw(a.queue, total);  // own range exhausted: steal
+                posted = true;
+            }
+        } else {
+            Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
+        }
         const int mbase = cur.m0 + wm * 64, nn = cur.n0 + wn * 64 + ecol;
         const int nc = min(nn, a.N - 8);
         float x[HAS_AUX ? 8 : 1][8];
@@ -388,6 +454,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         cur = nxt;
         L = Ln;
     }
+    if (dyn && tid == 0) ntq_retire(a.queue, G);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -441,7 +508,8 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         const int row = 48 * wave + 8 * q + (lane >> 3);
         voffW[q] = (unsigned)(((size_t)row * a.ldw + (((lane & 7) ^ swz64(row)) * 8)) * 2);
     }
-    auto issue = [&](int m0, int n0, int kt, unsigned stage_base) {
+    auto issue = [&](int m0_, int n0_, int kt, unsigned stage_base) {
+        const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);  // uniform by construction
         const bf16_t* ab = a.A + (size_t)m0 * a.lda + kt * N3_BK;  // scalar
         const bf16_t* wb = a.W + (size_t)n0 * a.ldw + kt * N3_BK;
         if (m0 + N3_BM <= a.M) {
@@ -459,12 +527,46 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         for (int q = 0; q < 6; ++q) glds16s(wb, voffW[q], stage_base + dmaW + q * 1024);
     };
 
-    int L = pos;
-    if (L >= total) return;
+    // Tile order.  Static: round k, workgroup w -> tile k*G + pos(w).  Dynamic (a.queue): every XCD owns a contiguous range of the
+    // tiles (so the column tiles of an A row-panel still meet in one L2) and its workgroups draw from it with an atomic counter,
+    // then steal from the other ranges.  A workgroup that gets its CU late — another kernel (RCCL's all-reduce during the
+    // data-parallel backward) was holding it — then finds little or nothing left instead of a fixed 1/G share: with 8 CU slots
+    // taken the static walk measured 116 -> 190 us (tools/hog_probe.py).  Thread 0 draws the tile after next during the epilogue
+    // and posts it in the slab buffer's unused tail; everybody picks it up after the next tile's first barrier.
+    const bool dyn = a.queue != nullptr;
+    constexpr int QWORD = NTQ_WORD;
+    auto draw = [&]() -> int { return ntq_draw(a.queue, total); };  // thread 0 only
+    auto retire = [&]() {  // once per workgroup: the last one to finish re-arms the queue for the launch that reuses it
+        if (dyn && tid == 0) ntq_retire(a.queue, G);
+    };
+    int L, Lnext;
+    if (dyn) {
+        int* w = reinterpret_cast<int*>(smem);
+        if (tid == 0) {
+            const int t0 = draw();
+            w[0] = t0;
+            w[1] = t0 >= 0 ? draw() : -1;
+        }
+        __syncthreads();
+        L = __builtin_amdgcn_readfirstlane(w[0]);  // wave-uniform by construction; the DMA addressing wants scalars
+        Lnext = __builtin_amdgcn_readfirstlane(w[1]);
+        __syncthreads();  // everybody has read the two words before the first DMA lands on them
+    } else {
+        L = pos < total ? pos : -1;
+        Lnext = (L >= 0 && L + G < total) ? L + G : -1;
+    }
+    if (L < 0) {
+        retire();
+        return;
+    }
     int m0 = (L / tiles_n) * N3_BM, n0 = (L % tiles_n) * N3_BN;
     int g = 0;  // global stage counter: stage g lives in buffer g & 1
     issue(m0, n0, 0, smem_base);
     bool stores_behind = false;
+    bool posted = false;  // a drawn tile index waits in the previous slab buffer
+    unsigned drawn = 0;
+    const int qhome = blockIdx.x & 7;
+    const int qbase = ntq_base(total, qhome), qlen = ntq_base(total, qhome + 1) - qbase;
 
     for (;;) {
         f32x16 acc[2][6];
@@ -481,7 +583,12 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             if (kt == 0 && stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done with buffer (g+1)&1 (reads / slabs)
+            if (kt == 0 && posted) {  // pick up the tile index thread 0 posted during the last epilogue, before the DMA below reuses that buffer
+                Lnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(smem + ((g + 1) & 1) * N3_STAGE_BYTES + QWORD));
+                posted = false;
+            }
             if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
+            if (kt == 0 && dyn && Lnext >= 0 && tid == 0) drawn = atomicAdd(&a.queue[qhome], 1u);  // looked at in the epilogue
             const char* st = smem + (g & 1) * N3_STAGE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -500,9 +607,21 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: buffer (g-1)&1 now holds the slabs
 
         // ---- epilogue, overlapped with the first stage of the next tile (into the other buffer) ----
-        const int Ln = L + G;
-        const bool has_next = Ln < total;
+        const int Ln = Lnext;
+        const bool has_next = Ln >= 0;
         const int m0n = has_next ? (Ln / tiles_n) * N3_BM : 0, n0n = has_next ? (Ln % tiles_n) * N3_BN : 0;
+        // the index of the tile after next was drawn at the top of this tile's main loop (an atomic fired here instead made hipcc
+        // drain the prefetch and the store tail on every tile); post it for everybody in the slab buffer's unused tail
+        if (dyn) {
+            if (has_next) {
+                if (tid == 0)
+                    *reinterpret_cast<volatile int*>(smem + ((g + 1) & 1) * N3_STAGE_BYTES + QWORD) =
+                        (drawn < (unsigned)qlen) ? qbase + (int)drawn : draw();  // own range exhausted: steal
+                posted = true;
+            }
+        } else {
+            Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
+        }
         if (has_next) issue(m0n, n0n, 0, smem_base + (g & 1) * N3_STAGE_BYTES);
         float* ep = reinterpret_cast<float*>(smem + ((g + 1) & 1) * N3_STAGE_BYTES) + wave * 16 * EP_LD;
         const bool full = (m0 + N3_BM <= a.M);
@@ -543,6 +662,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         n0 = n0n;
         L = Ln;
     }
+    retire();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -861,6 +981,21 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
 
 }  // namespace
 
+// Dynamic tile queues: a pool of 16-word slots in device memory (zeroed once; every launch re-arms its slot when its last
+// workgroup retires), handed out round-robin.  256 slots against ~100 GEMM launches per step on one stream: a slot is never
+// shared by two launches in flight.  The slot index is fixed at launch time, so a captured HIP graph replays consistently.
+static unsigned* nt_queue_slot() {
+    static unsigned* pool = nullptr;
+    static unsigned seq = 0;
+    const char* e = getenv("DCV_NT_DYNAMIC");  // read per call: dp.DataParallel switches it on for the multi-GPU run
+    if (!(e && e[0] == '1')) return nullptr;
+    if (!pool) {
+        if (hipMalloc((void**)&pool, 256 * 16 * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(pool, 0, 256 * 16 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    }
+    return pool + 16 * (seq++ & 255);
+}
+
 extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue,
                            const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
                            const float* aux2, int T, int n, void* stream) {
@@ -869,7 +1004,7 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
     // DCV_NT_GRID: measurement knob (tools/stagger_probe.sh runs the persistent kernel on fewer CUs); default = every CU
     static const int grid_cap = (getenv("DCV_NT_GRID") && atoi(getenv("DCV_NT_GRID")) > 0) ? atoi(getenv("DCV_NT_GRID")) : 256;
-    GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n};
+    GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n, nullptr};
     int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
     if (grid > grid_cap) grid = grid_cap;  // persistent: one 144 KB workgroup per CU walks the tiles
     hipStream_t s = (hipStream_t)stream;
@@ -882,6 +1017,7 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     if (use384) {
         int g3 = ((M + N3_BM - 1) / N3_BM) * (N / N3_BN);
         if (g3 > grid_cap) g3 = grid_cap;
+        a.queue = nt_queue_slot();  // null unless DCV_NT_DYNAMIC=1
         switch (epilogue) {
             case DCV_EPI_BIAS_BF16:
                 if (!bias) return DCV_ERR_NULL;
@@ -908,6 +1044,7 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
         DCV_LAUNCH_CHECK();
         return DCV_OK;
     }
+    a.queue = nt_queue_slot();
     switch (epilogue) {
         case DCV_EPI_BIAS_BF16:
             if (!bias) return DCV_ERR_NULL;

@@ -131,6 +131,10 @@ int dcv_cast_bf16_sr(const float* src, void* dst, long n, const unsigned* seed_d
 int dcv_cast_transpose_bf16_sr(const float* src_base, void* dst_base, const long long* desc_dev, int n_desc, int max_tiles,
                                const unsigned* seed_dev, void* stream);
 
+/* measurement aid: `wgs` workgroups of 256 threads and `lds_bytes` of LDS each spin for ~kcycles*1000 clocks (a stand-in for a
+ * communication kernel occupying CUs beside the step; tools/hog_probe.py) */
+int dcv_debug_hog(int wgs, int lds_bytes, int kcycles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
