@@ -594,15 +594,29 @@ class DiChaViT(nn.Module):
         return ga[o:o + p.numel()].view(p.shape)
 
     def _run_backward(self, st, dfeat, dstats):
+        ga = self._new_grad_arena()
+        g = lambda p: self._gview(ga, p)  # noqa: E731
+        dp = self._dp
+        # Data parallel: RCCL's all-reduce kernels run beside this backward.  The 256 x 384 GEMM kernel owns all 160 KB of a CU's
+        # LDS, so ANY co-resident kernel delays its workgroups (tools/hog_probe.py: 113 -> 190 us with 8 CU slots taken); the
+        # 256 x 128 kernel (144 KB) shares a CU with a small-LDS kernel at no cost.  While collectives are in flight the backward
+        # therefore uses the latter (DCV_NT384 is read per GEMM call); the forward, where nothing else runs, keeps the wide tiles.
+        nt384_prev = os.environ.get("DCV_NT384")
+        if dp is not None and (dp.world > 1 or dp._force) and nt384_prev is None:
+            os.environ["DCV_NT384"] = "0"
+        try:
+            return self._run_backward_body(st, dfeat, dstats, ga, g, dp)
+        finally:
+            if nt384_prev is None:
+                os.environ.pop("DCV_NT384", None)
+
+    def _run_backward_body(self, st, dfeat, dstats, ga, g, dp):
         fe = self.feature_extractor
         D, H = self.dim, fe.num_heads
         B, C, n, N, M = st["B"], st["C"], st["n"], st["N"], st["M"]
         T = C * n
         dev = dfeat.device
         bf, f32 = torch.bfloat16, torch.float32
-        ga = self._new_grad_arena()
-        g = lambda p: self._gview(ga, p)  # noqa: E731
-        dp = self._dp
         # --- final LayerNorm (CLS rows) ---
         fs = st["final_stride"]
         compact = fs == D  # the last block ran on the CLS rows only: its gradients are [B, D] until its attention
