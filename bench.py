@@ -113,6 +113,8 @@ def main():
         os.environ["NCCL_DEBUG"] = os.environ.get("DCV_NCCL_DEBUG", "WARN")  # no RCCL version banner on stdout: ONE JSON line
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29655"
+        from diverse_channel_vit_amd.dp import DataParallel as _DP
+        _DP.limit_rccl_channels(8)  # before the communicator exists; see dp.py
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import diverse_channel_vit_amd as dcv

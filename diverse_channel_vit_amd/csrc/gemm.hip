@@ -1002,8 +1002,10 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     if (!A || !W || !out) return DCV_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
-    // DCV_NT_GRID: measurement knob (tools/stagger_probe.sh runs the persistent kernel on fewer CUs); default = every CU
-    static const int grid_cap = (getenv("DCV_NT_GRID") && atoi(getenv("DCV_NT_GRID")) > 0) ? atoi(getenv("DCV_NT_GRID")) : 256;
+    // DCV_NT_GRID (read per call): number of persistent workgroups.  Default: every CU.  The data-parallel backward lowers it
+    // while RCCL's kernels hold CUs (dichavit.py); tools/stagger_probe.sh uses it to run the kernel on fewer CUs.
+    const char* genv = getenv("DCV_NT_GRID");
+    const int grid_cap = (genv && atoi(genv) > 0) ? atoi(genv) : 256;
     GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n, nullptr};
     int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
     if (grid > grid_cap) grid = grid_cap;  // persistent: one 144 KB workgroup per CU walks the tiles

@@ -597,18 +597,27 @@ class DiChaViT(nn.Module):
         ga = self._new_grad_arena()
         g = lambda p: self._gview(ga, p)  # noqa: E731
         dp = self._dp
-        # Data parallel: RCCL's all-reduce kernels run beside this backward.  The 256 x 384 GEMM kernel owns all 160 KB of a CU's
-        # LDS, so ANY co-resident kernel delays its workgroups (tools/hog_probe.py: 113 -> 190 us with 8 CU slots taken); the
-        # 256 x 128 kernel (144 KB) shares a CU with a small-LDS kernel at no cost.  While collectives are in flight the backward
-        # therefore uses the latter (DCV_NT384 is read per GEMM call); the forward, where nothing else runs, keeps the wide tiles.
-        nt384_prev = os.environ.get("DCV_NT384")
-        if dp is not None and (dp.world > 1 or dp._force) and nt384_prev is None:
-            os.environ["DCV_NT384"] = "0"
+        # Data parallel: RCCL's all-reduce kernels run beside this backward, one workgroup per channel with 21 KB of LDS each
+        # (read from librccl's gfx950 code object).  Neither NT GEMM kernel can share a CU with one (144 KB / 160 KB of the 160),
+        # and both deal their tiles statically to one workgroup per CU, so a workgroup whose CU is taken starts late and the
+        # whole GEMM waits for it (tools/hog_probe.py: 113 -> 190 us with 8 CU slots taken).  While collectives can be in
+        # flight the backward therefore (a) stays on the 256 x 128 kernel and (b) launches 8 workgroups fewer than there are CUs
+        # — dp.DataParallel asks RCCL for at most 8 channels — so that every workgroup finds a free CU at once.  Both knobs are
+        # read per GEMM call; the forward, where nothing else runs, keeps the wide tiles and the full grid.
+        saved = {k: os.environ.get(k) for k in ("DCV_NT384", "DCV_NT_GRID")}
+        guard = dp is not None and (dp.world > 1 or dp._force)
+        if guard:
+            if saved["DCV_NT384"] is None:
+                os.environ["DCV_NT384"] = "0"
+            if saved["DCV_NT_GRID"] is None:
+                os.environ["DCV_NT_GRID"] = str(256 - dp.reserved_cus)
         try:
             return self._run_backward_body(st, dfeat, dstats, ga, g, dp)
         finally:
-            if nt384_prev is None:
-                os.environ.pop("DCV_NT384", None)
+            if guard:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
 
     def _run_backward_body(self, st, dfeat, dstats, ga, g, dp):
         fe = self.feature_extractor

@@ -23,6 +23,18 @@ import torch.distributed as dist
 
 
 class DataParallel:
+    #: CUs the backward leaves to RCCL's kernels (dichavit.py, _run_backward); matches the channel cap `limit_rccl_channels` sets
+    reserved_cus = 8
+
+    @staticmethod
+    def limit_rccl_channels(n: int = 8) -> None:
+        """Call BEFORE torch.distributed.init_process_group: caps RCCL at `n` channels (= workgroups = CUs held during an
+        all-reduce) unless the user already chose.  86 MB of gradients per ~40 ms step need a small fraction of the xGMI
+        bandwidth, while every CU RCCL holds stalls a persistent GEMM workgroup."""
+        import os
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(n, 4)))
+
     def __init__(self, model, process_group=None, min_bucket_bytes: int = 4 << 20, force_collectives: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")

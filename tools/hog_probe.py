@@ -32,6 +32,6 @@ cases = {"nt384 qkv": lambda: hip.gemm_nt(A, W, hip.EPI_BIAS_BF16, out, bias=bia
          "attn fwd": lambda: hip.attn_fwd(qkv, o, lse, B, N, H, 64, 0.125)}
 for name, fn in cases.items():
     row = {}
-    for wgs, lds in ((0, 0), (8, 1024), (8, 65536), (32, 1024), (32, 65536)):
+    for wgs, lds in ((0, 0), (8, 1024), (8, 21184), (8, 65536), (32, 1024), (32, 21184), (32, 65536)):  # 21184 B: RCCL's device kernels
         row[f"{wgs}x{lds // 1024}K"] = round(timed(fn, wgs, lds))
     print(name, json.dumps(row), flush=True)
