@@ -9,13 +9,25 @@ One step = one pass of the hot path over one synthetic batch already resident in
 zero_grad -> forward (tokeniser, 12 blocks, regularisers) -> CE + extra -> backward (+ RCCL gradient
 all-reduce overlapped with backward when N > 1) -> fused AdamW.  The reference's three per-step
 ``.item()`` logging syncs (trainer.py:1021-1027) are NOT included (the loss stays on the device).
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the dominant
-kernel (timed live with events on the launch stream) and `cpu_baseline` (the oracle = our CPU
-restatement of the reference, "port", timed on this box's host cores on a bounded sample).
+
+Prints ONE JSON line on rank 0 (contract in the task statement):
+  * value / ms_per_step : wall clock over EXACTLY K steps between barrier + synchronize pairs, max over ranks;
+    median_ms_per_step  : median of the K per-step event intervals (value_median = the rate it gives);
+  * roofline            : the dominant kernel SYMBOL (largest share of a step, found in the profiled warm-up steps), its
+    launches bracketed by HIP events on the launch stream INSIDE the timed region, achieved = algorithmic FLOPs (or bytes) of
+    that launch / mean event interval; `executed_*` = the FLOPs the kernel really performs (S recomputed in the attention
+    backward); `algorithmic_bytes` and `traffic` (HBM bytes per launch from the committed rocprofv3 --pmc passes of the
+    newest profiles/rNN_vM_pmc_traffic.json, FETCH_SIZE x2 + WRITE_SIZE per the gfx950 correction);
+  * kernel_table        : one row per kernel symbol and problem shape from the profiled warm-up steps (every C-ABI launch
+    bracketed by events): launches/step, mean us, FLOPs and algorithmic bytes per launch, achieved rate and fraction of the
+    MFMA / HBM peak, share of the step — so the worst kernel is named;
+  * cpu_baseline        : the oracle (CPU restatement of the reference, "port") timed on this box's host cores.
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -26,7 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15  # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12   # HBM3E spec (6.29 TB/s measured with a float4 copy), MI355X_MICROARCH.md
 TRAIN_GFLOP_PER_IMG = 336.94  # BASELINE.md §3 (matmul-only, train = 3 x fwd)
+DEAD_GFLOP_PER_IMG = 23.82    # rows of the last block that never reach the output
 
 
 class Cfg(dict):
@@ -43,8 +57,9 @@ def model_cfg(arch="small", channels=8, img=224, patch=16, classes=161):
                in_channel_names=[f"c{i}" for i in range(channels)], img_size=[img], num_classes=classes)
 
 
-def cpu_baseline(cfg, channels, img, classes, sample_bs=2, steps=2):
-    """The oracle (CPU restatement of the reference's path, fp32) timed on this host: baseline only."""
+def cpu_baseline(cfg, channels, img, classes, sample_bs=8, steps=3):
+    """The oracle (CPU restatement of the reference's path, fp32) timed on this host: baseline only (BASELINE.md §4:
+    1 warm-up + >= 3 timed steps at batch 8, the rate scales linearly with the batch)."""
     from oracle import dichavit_oracle as orc
     # the box's CPU share, not the host's core count (an oversubscribed pool is many times slower)
     try:
@@ -75,7 +90,43 @@ def cpu_baseline(cfg, channels, img, classes, sample_bs=2, steps=2):
             times.append(time.time() - t0)
     dt = float(np.median(times))
     return {"value": round(sample_bs / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed fp32 train steps (after 1 warm-up) of the same model at batch {sample_bs} on the host CPU"}
+            "sample": f"median of {steps} timed fp32 train steps (after 1 warm-up) of the same model at batch {sample_bs} on the host CPU "
+                      f"({dt:.1f} s per step)"}
+
+
+def newest_pmc_file():
+    """profiles/rNN_vM_pmc_traffic.json with the highest (round, version) — numeric, not lexicographic."""
+    best, best_key = None, None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")):
+        m = re.match(r"r(\d+)_v(\d+)_pmc_traffic\.json$", os.path.basename(f))
+        key = (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+        if best_key is None or key > best_key or (key == best_key and os.path.getmtime(f) > os.path.getmtime(best)):
+            best, best_key = f, key
+    return best
+
+
+def table_from(prof, n_steps, step_ms):
+    """rows per (symbol, shape) from hip.set_profiler records taken over n_steps eager steps"""
+    rows = []
+    for (sym, shape), r in prof.items():
+        ts = [s.elapsed_time(e) for s, e in r["ev"]]
+        if not ts:
+            continue
+        avg = float(np.mean(ts))
+        row = {"symbol": sym, "shape": shape, "launches_per_step": round(len(ts) / n_steps, 2), "avg_us": round(avg * 1e3, 1),
+               "ms_per_step": round(sum(ts) / n_steps, 3), "share_of_step": round(sum(ts) / n_steps / step_ms, 4)}
+        if r["flops"] > 0:
+            row.update(bound="mfma", gflop=round(r["flops"] / 1e9, 2), gflop_executed=round(r["flops_exec"] / 1e9, 2),
+                       achieved_tflops=round(r["flops"] / (avg * 1e-3) / 1e12, 1), frac=round(r["flops"] / (avg * 1e-3) / PEAK_BF16, 4),
+                       frac_executed=round(r["flops_exec"] / (avg * 1e-3) / PEAK_BF16, 4))
+        if r["bytes"] > 0:
+            row.update(algorithmic_mbytes=round(r["bytes"] / 1e6, 1), achieved_gbps=round(r["bytes"] / (avg * 1e-3) / 1e9, 0),
+                       hbm_frac=round(r["bytes"] / (avg * 1e-3) / PEAK_HBM, 4))
+            if r["flops"] <= 0:
+                row["bound"] = "hbm"
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows
 
 
 def main():
@@ -89,9 +140,13 @@ def main():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--classes", type=int, default=161)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-table", action="store_true", help="print the per-entry time table of one step to stderr")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the HIP-graph-captured step (N=1 only)")
+    ap.add_argument("--kernel-table", action="store_true", help="also print the per-symbol table to stderr")
+    ap.add_argument("--graph", action="store_true", help="N=1: replay a HIP-graph capture of the step (about 1 %% faster than eager launches); the "
+                                                         "dominant kernel's events then come from the profiled warm-up steps, not from the timed region")
+    ap.add_argument("--no-graph", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--force-dp", action="store_true", help="exercise the N>1 code path on one GPU: RCCL group of world size 1, collectives forced")
+    ap.add_argument("--grad-dtype", default="float32", choices=["float32", "bfloat16"], help="N>1: dtype the gradient buckets travel in")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: one all-reduce after the backward instead of per-layer buckets beside it")
     ap.add_argument("--hcs", action="store_true", help="secondary run (SURVEY §8d): enable_sample=True, hcs_sampling=lowest_cosine_prob, temp 1000 "
                                                      "(variable sequence length, one host sync per step like the reference)")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant (never the headline value): every step's batch comes from pinned "
@@ -109,12 +164,17 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     use_dp = world > 1 or args.force_dp
+    rccl_log = None
     if use_dp:
-        os.environ["NCCL_DEBUG"] = os.environ.get("DCV_NCCL_DEBUG", "WARN")  # no RCCL version banner on stdout: ONE JSON line
+        # RCCL's INIT log goes to a file (ONE JSON line on stdout): rank 0 parses the channel count actually set up from it
+        rccl_log = f"/tmp/dcv_rccl_{os.getpid()}.log"
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29655"
         from diverse_channel_vit_amd.dp import DataParallel as _DP
-        _DP.limit_rccl_channels(8)  # before the communicator exists; see dp.py
+        _DP.limit_rccl_channels(_DP.reserved_cus)  # before the communicator exists; see dp.py
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import diverse_channel_vit_amd as dcv
@@ -130,13 +190,12 @@ def main():
     torch.manual_seed(0)
     model = dcv.dichavit(cfg, mapper={"train": list(range(args.channels))}).to(dev)
     model.train()
-    model._ensure_arena(dev)
     dp = None
-    if use_dp:
-        dp = dcv.DataParallel(model, force_collectives=args.force_dp)
+    if use_dp:  # INTEGRATION.md's call order: wrap, equalise, hook — all before the first forward
+        dp = dcv.DataParallel(model, force_collectives=args.force_dp, grad_dtype=getattr(torch, args.grad_dtype), overlap=not args.no_overlap)
         dp.broadcast_parameters(0)
         dp.hook_misc_params()
-    use_graph = (world == 1) and not args.no_graph and not use_dp and not args.hcs
+    use_graph = args.graph and (world == 1) and not use_dp and not args.hcs
     opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=4.9e-5, betas=(0.9, 0.999), eps=1e-8,
                        weight_decay=0.04, model=model, capturable=use_graph)
     rs = np.random.RandomState(1234 + rank)
@@ -163,31 +222,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ENTRIES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkdv", "ln_fwd", "ln_bwd"]
-    for _ in range(max(args.warmup - 1, 0)):
+    # ---- warm-up: plain steps, then 1-2 fully profiled eager steps (every C-ABI launch bracketed by events) ----
+    n_prof = 2 if args.warmup >= 3 else 1
+    for _ in range(max(args.warmup - n_prof, 0)):
         step()
-    # one profiled warm-up step: find the dominant kernel family
-    hip.set_profiler(ENTRIES)
-    step()
     torch.cuda.synchronize()
-    prof = hip.set_profiler(None)
-    tot = {k: sum(s.elapsed_time(e) for s, e in v) for k, v in prof.items()}
-    cnt = {k: len(v) for k, v in prof.items()}
-    dominant = max(tot, key=tot.get)
+    hip.set_profiler(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n_prof):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    prof = hip.set_profiler(False)
+    prof_step_ms = e0.elapsed_time(e1) / n_prof
+    table = table_from(prof, n_prof, prof_step_ms)
+    by_symbol = {}
+    for r in table:
+        by_symbol[r["symbol"]] = by_symbol.get(r["symbol"], 0.0) + r["ms_per_step"]
+    dominant = max(by_symbol, key=by_symbol.get)
     if args.kernel_table and rank == 0:
-        for k in sorted(tot, key=tot.get, reverse=True):
-            print(f"  {k:16s} {cnt[k]:4d} launches  {tot[k]:9.3f} ms/step", file=sys.stderr)
+        for r in table:
+            print(f"  {r['symbol']:28s} {r['shape']:26s} x{r['launches_per_step']:5.1f} {r['avg_us']:8.1f} us  {r['ms_per_step']:7.3f} ms/step "
+                  f"{100 * r['share_of_step']:5.1f} %  " + (f"{r.get('achieved_tflops', 0):7.1f} TF/s ({100 * r.get('frac', 0):4.1f} % alg / "
+                  f"{100 * r.get('frac_executed', 0):4.1f} % exec)" if r.get("bound") == "mfma" else f"{r.get('achieved_gbps', 0):7.0f} GB/s"), file=sys.stderr)
 
-    # timed region.  Eager: events only around the dominant kernel's launches.  Graph: the whole step is one captured
-    # HIP graph (no launch gaps); the dominant kernel's duration then comes from the profiled eager step above
-    # (same kernels, same shapes), since events cannot be recorded inside a replayed graph.
+    # ---- timed region: EXACTLY K steps; events only around the dominant symbol's launches (eager) ----
     if use_graph:
         graphed(x, y)  # capture (plus its own eager warm-up steps)
         step = lambda: graphed(x, y)  # noqa: E731
         step()
-        hip.set_profiler(None)
     else:
-        hip.set_profiler([dominant])
+        hip.set_profiler(True, only=[dominant])
     if args.h2d:
         xh, yh = x.cpu().pin_memory(), y.cpu().pin_memory()
         bufs = [(torch.empty_like(x), torch.empty_like(y)) for _ in range(2)]
@@ -218,69 +284,78 @@ def main():
             loss = inner(x, y) if inner is not None else eager_step()
             consumed[slot].record()
             return loss
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
-    rec = prof[dominant] if use_graph else hip.set_profiler(None)[dominant]
+    live = None if use_graph else hip.set_profiler(False)
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    med_ms = float(np.median(step_ms))
     if use_dp:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt, med_ms = t[0].item(), t[1].item()
     final_loss = loss.item()
 
     if rank == 0:
         B, C, H = args.batch, args.channels, {"tiny": 3, "small": 6, "base": 12, "distill": 6}[args.arch]
         headline = (args.arch, C, args.img, args.batch, args.classes) == ("small", 8, 224, 64, 161) and not args.hcs
-        D = H * 64
         n = (args.img // 16) ** 2
         N = C * n + 1
-        M = B * N
-        per_launch_ms = float(np.mean([s.elapsed_time(e) for s, e in rec]))
-        prod = 2.0 * B * H * N * N * 64  # one N x N x 64 product over all (batch, head) pairs
-        # algorithmic FLOPs per launch: forward 2 products; backward 4 (dP, dV, dK, dQ; the S
-        # recompute is not counted): dkdv kernel is credited 3, dq kernel 1.  GEMMs: mean over the launches of a step.
-        flops = {"attn_fwd": 2 * prod, "attn_bwd_dkdv": 3 * prod, "attn_bwd_dq": 1 * prod,
-                 # per block: qkv 3 + proj 1 + fc1 4 + fc2 4 = 12 D^2-units forward, the same again for input grads
-                 "gemm_nt": (12 * 2.0 * M * D * D * 24 + 2.0 * B * C * n * 256 * D) / max(cnt["gemm_nt"], 1),
-                 "gemm_tn": (12 * 2.0 * M * D * D * 12 + 2.0 * B * C * n * 256 * D) / max(cnt["gemm_tn"], 1)}.get(dominant)
-        roof = None
-        if flops is not None:
-            ach = flops / (per_launch_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                    "frac": round(ach * 1e12 / PEAK_BF16, 4), "traffic": None, "avg_launch_ms": round(per_launch_ms, 4),
-                    "launches_timed": len(rec)}
+        # ---- roofline of the dominant symbol ----
+        src = live if live is not None else prof
+        recs = [(k, r) for k, r in src.items() if k[0] == dominant and r["ev"]]
+        ev_ms = [s.elapsed_time(e) for _, r in recs for s, e in r["ev"]]
+        n_l = len(ev_ms)
+        avg_ms = float(np.mean(ev_ms))
+        flops = sum(r["flops"] * len(r["ev"]) for _, r in recs) / n_l
+        flops_exec = sum(r["flops_exec"] * len(r["ev"]) for _, r in recs) / n_l
+        alg_bytes = sum(r["bytes"] * len(r["ev"]) for _, r in recs) / n_l
+        where = ("HIP events around every launch of this symbol inside the timed region" if live is not None else
+                 f"HIP events in the {n_prof} profiled eager warm-up step(s): the timed region replays a captured HIP graph")
+        if flops > 0:
+            ach = flops / (avg_ms * 1e-3)
+            roof = {"bound": "mfma", "kernel": dominant, "achieved": round(ach / 1e12, 2), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16, 4), "executed_achieved": round(flops_exec / (avg_ms * 1e-3) / 1e12, 2),
+                    "executed_frac": round(flops_exec / (avg_ms * 1e-3) / PEAK_BF16, 4),
+                    "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "executed_gflop_per_launch": round(flops_exec / 1e9, 2)}
         else:
-            bytes_ = {"ln_fwd": M * D * 6.0, "ln_bwd": M * D * (2 + 4 + 4 + 4 + 2.0)}[dominant]
-            ach = bytes_ / (per_launch_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 4), "traffic": None, "avg_launch_ms": round(per_launch_ms, 4), "launches_timed": len(rec)}
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure
-        # comes from the committed rocprofv3 --pmc passes over this same command at the headline configuration
-        # (tools/pmc_traffic.sh -> profiles/*_pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, per the gfx950 correction)
-        if headline and roof is not None:
-            import glob
-            files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
-            if files:
-                with open(files[-1]) as f:
-                    pmc = json.load(f)
-                tot = n_l = 0.0
-                for k, v in pmc.items():
-                    if k.split("<")[0].replace("_kernel", "").rstrip("0123456789") == dominant or k.startswith(dominant + "_kernel"):
-                        tot += v["launches"] * (v["read_bytes_per_launch"] + v["written_bytes_per_launch"])
-                        n_l += v["launches"]
-                if n_l:
-                    roof["traffic"] = round(tot / n_l)
-                    roof["traffic_unit"] = "bytes/launch (HBM, PMC)"
-                    roof["traffic_source"] = "profiles/" + os.path.basename(files[-1])
+            ach = alg_bytes / (avg_ms * 1e-3)
+            roof = {"bound": "hbm", "kernel": dominant, "achieved": round(ach / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM, 4)}
+        roof.update(traffic=None, algorithmic_bytes=round(alg_bytes), avg_launch_ms=round(avg_ms, 4), launches_timed=n_l,
+                    share_of_step=round(by_symbol[dominant] / prof_step_ms, 4), measured=where)
+        # HBM bytes per launch of that symbol: PMC counters cannot be read from inside this process, so the figure comes from
+        # the committed rocprofv3 --pmc passes over this same command at the headline configuration (tools/pmc_traffic.sh)
+        pmc_path = newest_pmc_file() if headline else None
+        pmc = {}
+        if pmc_path:
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            if dominant in pmc:
+                v = pmc[dominant]
+                roof["traffic"] = round(v["read_bytes_per_launch"] + v["written_bytes_per_launch"])
+                roof["traffic_unit"] = "bytes/launch (HBM, PMC: 2 x FETCH_SIZE + WRITE_SIZE)"
+                roof["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
+        for r in table:  # per-symbol PMC traffic next to the algorithmic bytes (mean over the symbol's shapes in the PMC run)
+            if r["symbol"] in pmc:
+                v = pmc[r["symbol"]]
+                r["pmc_mbytes_per_launch"] = round((v["read_bytes_per_launch"] + v["written_bytes_per_launch"]) / 1e6, 1)
+        exec_gf = TRAIN_GFLOP_PER_IMG - (DEAD_GFLOP_PER_IMG if model.cls_only_tail else 0.0)
         imgs = args.batch * world * args.steps / dt
+        imgs_med = args.batch * world / (med_ms * 1e-3)
+        small8 = (args.arch, C, args.img) == ("small", 8, 224)
         line = {
             "metric": ("train images/sec, DiChaViT-S 8ch 224^2 bs=64/GPU" if (args.arch, C, args.img, args.batch) == ("small", 8, 224, 64)
                        else f"train images/sec, DiChaViT-{args.arch} {C}ch {args.img}^2 bs={args.batch}/GPU"),
             "value": round(imgs, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "median_ms_per_step": round(med_ms, 3), "value_median": round(imgs_med, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"DiChaViT-{args.arch} {C}ch {args.img}x{args.img} P16 {args.classes} classes, train step "
                                    f"(fwd + CE + ortho/proxy regularisers + bwd + fused AdamW), bs {args.batch}/GPU, N={N} tokens",
@@ -288,25 +363,38 @@ def main():
                        # the reference's 336.94 GFLOP/img include the rows of the LAST block that never reach the output (everything
                        # after its attention on the non-CLS tokens, and all but the CLS query of that attention): 3 * (18 N D^2 +
                        # 4 N^2 D) (N-1)/N = 23.82 GFLOP/img that this path does not execute.  The fraction is quoted on EXECUTED FLOPs.
-                       "step_roofline_frac": round(imgs / world * (TRAIN_GFLOP_PER_IMG - (23.82 if model.cls_only_tail else 0.0)) * 1e9 / PEAK_BF16, 4)
-                       if (args.arch, C, args.img) == ("small", 8, 224) else None,
-                       "executed_gflop_per_img": round(TRAIN_GFLOP_PER_IMG - (23.82 if model.cls_only_tail else 0.0), 2) if (args.arch, C, args.img) == ("small", 8, 224) else None,
+                       "step_roofline_frac": round(imgs / world * exec_gf * 1e9 / PEAK_BF16, 4) if small8 else None,
+                       "executed_gflop_per_img": round(exec_gf, 2) if small8 else None,
                        "dead_rows": ("last block: token-wise ops after the attention on the CLS rows only, attention for the CLS query only "
                                      "(the encoder returns norm(x)[:, 0]; same outputs and gradients, DCV_CLS_TAIL=0 computes every row)"
                                      if model.cls_only_tail else "none skipped"),
-                       "final_loss": round(final_loss, 5), "input": ("pinned host memory -> HBM every step (copy stream, double-buffered)" if args.h2d else "resident in HBM"), "host_syncs_per_step": 0,
+                       "final_loss": round(final_loss, 5),
+                       "input": ("pinned host memory -> HBM every step (copy stream, double-buffered)" if args.h2d else "resident in HBM"),
+                       "host_syncs_per_step": 0,
                        "launch": "hip-graph replay of the captured step" if use_graph else "eager",
-                       **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)",
-                           "dp_buckets_per_step": None} if args.hcs else {}),
-                       **({"dp_buckets_launched": dp.buckets_launched} if dp is not None else {})},
+                       **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)"} if args.hcs else {})},
             "roofline": roof,
+            "kernel_table": table[:24],
         }
+        if dp is not None:
+            steps_run = args.warmup + args.steps
+            line["dp"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "buckets_launched": dp.buckets_launched,
+                          "buckets_per_step": round(dp.buckets_launched / max(steps_run, 1), 2),
+                          "mbytes_reduced_per_step": round(dp.bytes_reduced / max(steps_run, 1) / 1e6, 2), "grad_dtype": args.grad_dtype,
+                          "overlap": not args.no_overlap, "rccl_channels_requested": os.environ.get("NCCL_MAX_NCHANNELS"),
+                          "rccl_channels_in_use": dcv.DataParallel.rccl_channels_from_log(rccl_log) if rccl_log else None,
+                          "reserved_cus": dp.reserved_cus}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.channels, args.img, args.classes)
         print(json.dumps(line), flush=True)
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()
+        if rccl_log:
+            try:
+                os.remove(rccl_log)
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":

@@ -8,8 +8,8 @@ a CPU implementation: the first forward loads diverse_channel_vit_amd/libdcv_hip
 from .dichavit import DiChaViT, dichavit, proxy_loss  # noqa: F401
 from .dp import DataParallel  # noqa: F401
 from .optim import HipAdamW, clip_grad_norm_  # noqa: F401
-from .checkpoint import save_checkpoint, load_checkpoint, evaluate  # noqa: F401
+from .checkpoint import save_checkpoint, load_checkpoint, evaluate, dump_features, eval_subset_channels  # noqa: F401
 from .graph import GraphedTrainStep  # noqa: F401
 
 __all__ = ["DiChaViT", "dichavit", "proxy_loss", "DataParallel", "HipAdamW", "GraphedTrainStep", "clip_grad_norm_", "save_checkpoint", "load_checkpoint",
-           "evaluate"]
+           "evaluate", "dump_features", "eval_subset_channels"]

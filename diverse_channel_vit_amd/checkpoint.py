@@ -5,11 +5,18 @@ save_checkpoint / load_checkpoint write and read the dict that Trainer._save_mod
 resumed by either side.  Model keys may carry DataParallel/DDP's ``module.`` prefix (trainer.py:1313-1318); it is stripped or
 added as the target model requires.  ``evaluate`` is eval_regular's loop (trainer.py:385-449): eval mode, inference_mode,
 concatenated logits -> top-1 accuracy in percent, summed over ranks when torch.distributed is initialised (the
-reference's torchmetrics Accuracy does the same reduction)."""
+reference's torchmetrics Accuracy does the same reduction).  ``dump_features`` is the feature-extraction half of eval_morphem70k
+(trainer.py:645-690): per chunk, eval-mode forwards with the leave-one-out ``new_channel_init`` -> one ``.npy`` per chunk in the
+layout ``morphem.run_benchmark`` reads (the benchmark itself is the reference's, unchanged).  ``eval_subset_channels`` is the
+channel-subset sweep of trainer.py:474-545, including its mutation of ``patch_embed.mapper[chunk]``."""
 from __future__ import annotations
 
 import datetime
-from typing import Iterable, Optional
+import os
+from itertools import combinations
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
 
 import torch
 import torch.distributed as dist
@@ -95,3 +102,71 @@ def evaluate(model, batches: Iterable, chunk_name: str, training_chunks: Optiona
             dist.all_reduce(cpu)
             counts = cpu
     return float(counts[0] / counts[1] * 100.0)
+
+
+@torch.inference_mode()
+def dump_features(model, loaders: Dict[str, Iterable], feature_dir: str, feature_file: str = "features.npy",
+                  training_chunks: Optional[str] = None, new_channel_init: Optional[str] = None, init_first_layer=None,
+                  channel_combinations: Optional[Sequence[int]] = None, device=None) -> List[str]:
+    """eval_morphem70k's feature pass (trainer.py:645-690): for every chunk in ``loaders`` (e.g. Allen / HPA / CP) run the
+    model in eval mode over the chunk's batches — image tensors, as the CHAMMI test loaders yield (dicts with "image" are
+    accepted too) — with ``training_chunks`` and the leave-one-out ``new_channel_init``, concatenate the [b, D] feature
+    rows and write them with ``np.save`` to ``<feature_dir>/<chunk>/<feature_file>`` (utils.write_numpy, utils.py:232-235).
+    Returns the written paths; the caller hands ``feature_dir`` to ``morphem.benchmark.run_benchmark`` as the reference does."""
+    was_training = model.training
+    model.eval()
+    paths = []
+    for chunk_name, loader in loaders.items():
+        feats = []
+        for batch in loader:
+            x = batch["image"] if isinstance(batch, dict) else (batch[0] if isinstance(batch, (tuple, list)) else batch)
+            if device is not None:
+                x = x.to(device)
+            if channel_combinations is not None:
+                x = x[:, list(channel_combinations), :, :].clone()  # trainer.py:662-663
+            out = model(x, chunk_name, training_chunks, init_first_layer=init_first_layer, new_channel_init=new_channel_init)
+            feats.append(out.float().cpu())
+        folder = os.path.join(feature_dir, chunk_name)
+        os.makedirs(folder, exist_ok=True)
+        path = os.path.join(folder, feature_file)
+        np.save(path, torch.cat(feats, dim=0).numpy())
+        paths.append(path)
+    if was_training:
+        model.train()
+    return paths
+
+
+@torch.inference_mode()
+def eval_subset_channels(model, batches: Iterable, channels: Sequence[int], chunk_name: str = "test", only_sizes: Optional[Sequence[int]] = None,
+                         device=None) -> Dict[int, List[float]]:
+    """The channel-subset sweep of trainer.py:474-545: for n = len(channels) .. 1 and every combination of n channels, the
+    chunk's entry in ``patch_embed.mapper`` is REPLACED by the selected positions (:507-514), the batch is sliced to them and
+    the model evaluated (training_chunks=None, new_channel_init=""); returns {n: [top-1 % per combination]}.  The reference
+    breaks after the first n (:536); pass ``only_sizes`` to restrict, default = every size.  The mapper entry stays mutated, as
+    in the reference."""
+    was_training = model.training
+    model.eval()
+    batches = list(batches)
+    channels = list(channels)
+    mapper = model.feature_extractor.patch_embed.mapper
+    res: Dict[int, List[float]] = {}
+    for n_ch in range(len(channels), 0, -1):
+        if only_sizes is not None and n_ch not in only_sizes:
+            continue
+        accs = []
+        for selected in combinations(channels, n_ch):
+            sel = [channels.index(c) for c in selected]
+            correct = total = 0
+            for batch in batches:
+                x, y = (batch["image"], batch["label"]) if isinstance(batch, dict) else batch[:2]
+                if device is not None:
+                    x, y = x.to(device), y.to(device)
+                mapper[chunk_name] = sel
+                out = model(x[:, sel, :, :].clone(), chunk_name, None, init_first_layer=None, new_channel_init="")
+                correct += int((out.argmax(dim=-1) == y).sum())
+                total += y.numel()
+            accs.append(100.0 * correct / max(total, 1))
+        res[n_ch] = accs
+    if was_training:
+        model.train()
+    return res

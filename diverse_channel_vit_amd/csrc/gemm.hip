@@ -9,10 +9,9 @@
 //            of the same layers.  Reduction dim is the long one (M = B*N tokens): split over
 //            workgroups, fp32 atomics into the gradient arena.
 //
-// Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 tiles.
-// Register-staged double-buffered LDS (global loads for tile t+1 are issued before the MFMAs of
-// tile t and written to LDS after them: one barrier per K-tile).
-#include <stdlib.h>
+// gemm_nt: persistent 256x128 (8 waves, 3-stage LDS-DMA ring) and 256x384 (two 80 KB stages) kernels, geometry below.
+// gemm_tn: 128x128 register-staged kernel (4 waves) and the 384x128 LDS-DMA ring kernel (8 waves).
+#include <atomic>
 #include "dcv_common.hpp"
 #include "../../include/dcv.h"
 
@@ -35,7 +34,6 @@ struct GemmNtArgs {
     int ldaux;
     const float* aux2;
     int T, n;
-    unsigned* queue;  // dynamic tile queue of this launch (9 words: next index of each XCD's range, finished workgroups) or null
 };
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7: far below the bf16 rounding of the outputs), sharing
@@ -206,29 +204,6 @@ __device__ constexpr int nt_stores_per_wave() {
     return (EPI == DCV_EPI_BIAS_GELU_BF16 || EPI == DCV_EPI_BIAS_RESID_F32) ? 16 : 8;
 }
 
-// ---- dynamic tile queue (both persistent NT kernels) -------------------------------------------------------------------
-// queue[0..7]: next index inside each XCD's contiguous tile range; queue[8]: workgroups that have retired.  See gemm_nt384.
-__device__ __forceinline__ int ntq_base(int total, int x) { return (int)((long long)total * x / 8); }
-__device__ int ntq_draw(unsigned* queue, int total) {  // one thread per workgroup
-    const int home = blockIdx.x & 7;
-    for (int y = 0; y < 8; ++y) {
-        const int xx = (home + y) & 7;
-        const int base = ntq_base(total, xx), len = ntq_base(total, xx + 1) - base;
-        if (len <= 0) continue;
-        const unsigned i = atomicAdd(&queue[xx], 1u);
-        if (i < (unsigned)len) return base + (int)i;
-    }
-    return -1;
-}
-__device__ __forceinline__ void ntq_retire(unsigned* queue, int G) {  // one thread per workgroup, once
-    __threadfence();
-    if (atomicAdd(&queue[8], 1u) == (unsigned)G - 1) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) queue[i] = 0u;
-    }
-}
-constexpr int NTQ_WORD = 36864;  // byte offset of the posted tile index inside a ring buffer (the epilogue slabs end at 34816)
-
 struct NtTile {
     const bf16_t* gA[4];
     const bf16_t* gW[2];
@@ -292,32 +267,10 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     constexpr int EP_LD = 68;  // floats per slab row (272 B: 16-byte aligned, rows shifted by 4 banks)
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
 
-    // tile order: static (round k, workgroup w -> k*G + pos(w)) or drawn from the launch's queue (a.queue; gemm_nt384 explains why)
-    const bool dyn = a.queue != nullptr;
-    int L, Lnext;
-    if (dyn) {
-        int* w = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            const int t0 = ntq_draw(a.queue, total);
-            w[0] = t0;
-            w[1] = t0 >= 0 ? ntq_draw(a.queue, total) : -1;
-        }
-        __syncthreads();
-        L = __builtin_amdgcn_readfirstlane(w[0]);
-        Lnext = __builtin_amdgcn_readfirstlane(w[1]);
-        __syncthreads();
-    } else {
-        L = pos < total ? pos : -1;
-        Lnext = (L >= 0 && L + G < total) ? L + G : -1;
-    }
-    if (L < 0) {
-        if (dyn && tid == 0) ntq_retire(a.queue, G);
-        return;
-    }
-    bool posted = false;
-    unsigned drawn = 0;
-    const int qhome = blockIdx.x & 7;
-    const int qbase = ntq_base(total, qhome), qlen = ntq_base(total, qhome + 1) - qbase;
+    // tile order: round k, workgroup w -> k*G + pos(w)
+    int L = pos < total ? pos : -1;
+    int Lnext = (L >= 0 && L + G < total) ? L + G : -1;
+    if (L < 0) return;
     NtTile cur, nxt;
     nt_tile_setup(a, L, tiles_n, wave, lane, cur);
     int g = 0;  // global stage counter of this workgroup: stage g lives in ring buffer g % 3
@@ -358,15 +311,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();  // everyone's stage g landed; everyone is done with buffer (g-1)%3 (reads and slabs)
-            if (kt == 0 && posted) {  // the tile index posted in the last epilogue's slab buffer, before the DMA below reuses it
-                Lnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(smem + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES + NTQ_WORD));
-                posted = false;
-            }
             if (kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
-            // the tile after next: thread 0 fires the atomic on its XCD's range here, a whole main loop before the result is looked
-            // at (at the start of the epilogue, where nothing of ours is in flight).  Fired in the epilogue instead, hipcc's wait
-            // for it drained the prefetched stages and the store tail on every tile: +20 % on the short K = 384, N = 384 product.
-            if (kt == 0 && dyn && Lnext >= 0 && tid == 0) drawn = atomicAdd(&a.queue[qhome], 1u);
             const char* st = smem + (g % NT_STAGES) * NT_STAGE_BYTES;
 #if DCV_GABL != 2
 #pragma unroll
@@ -392,16 +337,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         // ---- epilogue of `cur`, overlapped with the first two stages of the next tile ----
         const int Ln = Lnext;
         const bool has_next = Ln >= 0;
-        if (dyn) {
-            if (has_next) {
-                if (tid == 0)
-                    *reinterpret_cast<volatile int*>(smem + ((g + NT_STAGES - 1) % NT_STAGES) * NT_STAGE_BYTES + NTQ_WORD) =
-                        (drawn < (unsigned)qlen) ? qbase + (int)drawn : ntq_draw(a.queue, total);  // own range exhausted: steal
-                posted = true;
-            }
-        } else {
-            Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
-        }
+        Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
         const int mbase = cur.m0 + wm * 64, nn = cur.n0 + wn * 64 + ecol;
         const int nc = min(nn, a.N - 8);
         float x[HAS_AUX ? 8 : 1][8];
@@ -454,7 +390,6 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         cur = nxt;
         L = Ln;
     }
-    if (dyn && tid == 0) ntq_retire(a.queue, G);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -527,46 +462,14 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         for (int q = 0; q < 6; ++q) glds16s(wb, voffW[q], stage_base + dmaW + q * 1024);
     };
 
-    // Tile order.  Static: round k, workgroup w -> tile k*G + pos(w).  Dynamic (a.queue): every XCD owns a contiguous range of the
-    // tiles (so the column tiles of an A row-panel still meet in one L2) and its workgroups draw from it with an atomic counter,
-    // then steal from the other ranges.  A workgroup that gets its CU late — another kernel (RCCL's all-reduce during the
-    // data-parallel backward) was holding it — then finds little or nothing left instead of a fixed 1/G share: with 8 CU slots
-    // taken the static walk measured 116 -> 190 us (tools/hog_probe.py).  Thread 0 draws the tile after next during the epilogue
-    // and posts it in the slab buffer's unused tail; everybody picks it up after the next tile's first barrier.
-    const bool dyn = a.queue != nullptr;
-    constexpr int QWORD = NTQ_WORD;
-    auto draw = [&]() -> int { return ntq_draw(a.queue, total); };  // thread 0 only
-    auto retire = [&]() {  // once per workgroup: the last one to finish re-arms the queue for the launch that reuses it
-        if (dyn && tid == 0) ntq_retire(a.queue, G);
-    };
-    int L, Lnext;
-    if (dyn) {
-        int* w = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            const int t0 = draw();
-            w[0] = t0;
-            w[1] = t0 >= 0 ? draw() : -1;
-        }
-        __syncthreads();
-        L = __builtin_amdgcn_readfirstlane(w[0]);  // wave-uniform by construction; the DMA addressing wants scalars
-        Lnext = __builtin_amdgcn_readfirstlane(w[1]);
-        __syncthreads();  // everybody has read the two words before the first DMA lands on them
-    } else {
-        L = pos < total ? pos : -1;
-        Lnext = (L >= 0 && L + G < total) ? L + G : -1;
-    }
-    if (L < 0) {
-        retire();
-        return;
-    }
+    // tile order: round k, workgroup w -> tile k*G + pos(w)
+    int L = pos < total ? pos : -1;
+    int Lnext = (L >= 0 && L + G < total) ? L + G : -1;
+    if (L < 0) return;
     int m0 = (L / tiles_n) * N3_BM, n0 = (L % tiles_n) * N3_BN;
     int g = 0;  // global stage counter: stage g lives in buffer g & 1
     issue(m0, n0, 0, smem_base);
     bool stores_behind = false;
-    bool posted = false;  // a drawn tile index waits in the previous slab buffer
-    unsigned drawn = 0;
-    const int qhome = blockIdx.x & 7;
-    const int qbase = ntq_base(total, qhome), qlen = ntq_base(total, qhome + 1) - qbase;
 
     for (;;) {
         f32x16 acc[2][6];
@@ -583,12 +486,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             if (kt == 0 && stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done with buffer (g+1)&1 (reads / slabs)
-            if (kt == 0 && posted) {  // pick up the tile index thread 0 posted during the last epilogue, before the DMA below reuses that buffer
-                Lnext = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int*>(smem + ((g + 1) & 1) * N3_STAGE_BYTES + QWORD));
-                posted = false;
-            }
             if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
-            if (kt == 0 && dyn && Lnext >= 0 && tid == 0) drawn = atomicAdd(&a.queue[qhome], 1u);  // looked at in the epilogue
             const char* st = smem + (g & 1) * N3_STAGE_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -610,18 +508,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         const int Ln = Lnext;
         const bool has_next = Ln >= 0;
         const int m0n = has_next ? (Ln / tiles_n) * N3_BM : 0, n0n = has_next ? (Ln % tiles_n) * N3_BN : 0;
-        // the index of the tile after next was drawn at the top of this tile's main loop (an atomic fired here instead made hipcc
-        // drain the prefetch and the store tail on every tile); post it for everybody in the slab buffer's unused tail
-        if (dyn) {
-            if (has_next) {
-                if (tid == 0)
-                    *reinterpret_cast<volatile int*>(smem + ((g + 1) & 1) * N3_STAGE_BYTES + QWORD) =
-                        (drawn < (unsigned)qlen) ? qbase + (int)drawn : draw();  // own range exhausted: steal
-                posted = true;
-            }
-        } else {
-            Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
-        }
+        Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
         if (has_next) issue(m0n, n0n, 0, smem_base + (g & 1) * N3_STAGE_BYTES);
         float* ep = reinterpret_cast<float*>(smem + ((g + 1) & 1) * N3_STAGE_BYTES) + wave * 16 * EP_LD;
         const bool full = (m0 + N3_BM <= a.M);
@@ -662,7 +549,6 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         n0 = n0n;
         L = Ln;
     }
-    retire();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -981,92 +867,90 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
 
 }  // namespace
 
-// Dynamic tile queues: a pool of 16-word slots in device memory (zeroed once; every launch re-arms its slot when its last
-// workgroup retires), handed out round-robin.  256 slots against ~100 GEMM launches per step on one stream: a slot is never
-// shared by two launches in flight.  The slot index is fixed at launch time, so a captured HIP graph replays consistently.
-static unsigned* nt_queue_slot() {
-    static unsigned* pool = nullptr;
-    static unsigned seq = 0;
-    const char* e = getenv("DCV_NT_DYNAMIC");  // read per call: dp.DataParallel switches it on for the multi-GPU run
-    if (!(e && e[0] == '1')) return nullptr;
-    if (!pool) {
-        if (hipMalloc((void**)&pool, 256 * 16 * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(pool, 0, 256 * 16 * sizeof(unsigned)) != hipSuccess) return nullptr;
+// CU count of the current device, queried once per device (an immutable device property, cached; no allocation, no sync)
+static int dcv_cu_count() {
+    static std::atomic<int> cached[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
     }
-    return pool + 16 * (seq++ & 255);
+    return n;
 }
 
-extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue,
-                           const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
-                           const float* aux2, int T, int n, void* stream) {
+#define DCV_NT_CASES(KERNEL, G)                                                                        \
+    switch (epilogue) {                                                                                \
+        case DCV_EPI_BIAS_BF16:                                                                        \
+            if (!bias) return DCV_ERR_NULL;                                                            \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_BF16>, dim3(G), dim3(512), 0, s, a);                \
+            break;                                                                                     \
+        case DCV_EPI_BIAS_GELU_BF16:                                                                   \
+            if (!bias || !out2) return DCV_ERR_NULL;                                                   \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_GELU_BF16>, dim3(G), dim3(512), 0, s, a);           \
+            break;                                                                                     \
+        case DCV_EPI_BIAS_RESID_F32:                                                                   \
+            if (!bias) return DCV_ERR_NULL;                                                            \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_RESID_F32>, dim3(G), dim3(512), 0, s, a);           \
+            break;                                                                                     \
+        case DCV_EPI_PLAIN_BF16:                                                                       \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_PLAIN_BF16>, dim3(G), dim3(512), 0, s, a);               \
+            break;                                                                                     \
+        case DCV_EPI_GELU_BWD_BF16:                                                                    \
+            if (!aux) return DCV_ERR_NULL;                                                             \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_GELU_BWD_BF16>, dim3(G), dim3(512), 0, s, a);            \
+            break;
+
+// which kernel dcv_gemm_nt_ex launches for this problem (DCV_TILE_NARROW / DCV_TILE_WIDE), or a negative error for an illegal forced tile
+extern "C" int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile) {
+    if (tile < DCV_TILE_AUTO || tile > DCV_TILE_WIDE) return DCV_ERR_SHAPE;
+    const bool legal384 = (N % N3_BN) == 0 && epilogue != DCV_EPI_PATCH;
+    if (tile == DCV_TILE_WIDE) return legal384 ? DCV_TILE_WIDE : DCV_ERR_UNSUPPORTED;
+    if (tile == DCV_TILE_NARROW) return DCV_TILE_NARROW;
+    return (legal384 && M >= 4096 && (N >= 1152 || K >= 1152) && epilogue != DCV_EPI_GELU_BWD_BF16) ? DCV_TILE_WIDE : DCV_TILE_NARROW;
+}
+
+extern "C" int dcv_gemm_tn_pick(int M, int P, int Q, int tile) {
+    (void)M;
+    if (tile < DCV_TILE_AUTO || tile > DCV_TILE_WIDE) return DCV_ERR_SHAPE;
+    const bool legal384 = (P % 384) == 0 && (Q % 128) == 0;
+    if (tile == DCV_TILE_WIDE) return legal384 ? DCV_TILE_WIDE : DCV_ERR_UNSUPPORTED;
+    if (tile == DCV_TILE_NARROW) return DCV_TILE_NARROW;
+    return (legal384 && (P / 384) * (Q / 128) >= 6) ? DCV_TILE_WIDE : DCV_TILE_NARROW;
+}
+
+extern "C" int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue,
+                              const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
+                              const float* aux2, int T, int n, int grid_cap, int tile, void* stream) {
     if (!A || !W || !out) return DCV_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
-    // DCV_NT_GRID (read per call): number of persistent workgroups.  Default: every CU.  The data-parallel backward lowers it
-    // while RCCL's kernels hold CUs (dichavit.py); tools/stagger_probe.sh uses it to run the kernel on fewer CUs.
-    const char* genv = getenv("DCV_NT_GRID");
-    const int grid_cap = (genv && atoi(genv) > 0) ? atoi(genv) : 256;
-    GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n, nullptr};
-    int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
-    if (grid > grid_cap) grid = grid_cap;  // persistent: one 144 KB workgroup per CU walks the tiles
+    if (grid_cap < 0 || tile < DCV_TILE_AUTO || tile > DCV_TILE_WIDE) return DCV_ERR_SHAPE;
+    // persistent kernels: one workgroup per CU walks the tiles; grid_cap (> 0) lowers the number of workgroups — the data-parallel
+    // backward leaves CUs to RCCL's kernels this way (dichavit.py), tests force multi-round walks on small problems
+    const int cap = grid_cap > 0 ? grid_cap : dcv_cu_count();
+    GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n};
     hipStream_t s = (hipStream_t)stream;
     // 256 x 384 tiles where they pay (measured, M = 100 416, against the 256 x 128 kernel): N = 1152 K = 384: 121 -> 107 us;
     // N = 1536 K = 384 + GELU: 238 -> 218; N = 384 K = 1536: 192 -> 184 (+residual), 154 -> 138 (plain); but N = 384 K = 384:
-    // 96 -> 101 (393 tiles on 256 CUs: two rounds for 1.5 rounds of work), and the GELU-backward epilogue (N = 1536, HBM-heavy: 616 MB in + out) 212 -> 220.  DCV_NT384 = 0 / 1 forces never / always.
-    const char* n3env = getenv("DCV_NT384");  // read per call: tests switch it
-    const bool legal384 = (N % N3_BN) == 0 && epilogue != DCV_EPI_PATCH && M >= 4096;
-    const bool use384 = legal384 && (n3env && n3env[0] ? n3env[0] == '1' : ((N >= 1152 || K >= 1152) && epilogue != DCV_EPI_GELU_BWD_BF16));
-    if (use384) {
+    // 96 -> 101 (393 tiles on 256 CUs: two rounds for 1.5 rounds of work), and the GELU-backward epilogue (N = 1536, HBM-heavy:
+    // 616 MB in + out) 212 -> 220.  tile = DCV_TILE_WIDE forces the 256 x 384 kernel wherever it is legal, DCV_TILE_NARROW never uses it.
+    const int pick = dcv_gemm_nt_pick(M, N, K, epilogue, tile);
+    if (pick < 0) return pick;
+    if (pick == DCV_TILE_WIDE) {
         int g3 = ((M + N3_BM - 1) / N3_BM) * (N / N3_BN);
-        if (g3 > grid_cap) g3 = grid_cap;
-        a.queue = nt_queue_slot();  // null unless DCV_NT_DYNAMIC=1
-        switch (epilogue) {
-            case DCV_EPI_BIAS_BF16:
-                if (!bias) return DCV_ERR_NULL;
-                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_BIAS_BF16>, dim3(g3), dim3(512), 0, s, a);
-                break;
-            case DCV_EPI_BIAS_GELU_BF16:
-                if (!bias || !out2) return DCV_ERR_NULL;
-                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_BIAS_GELU_BF16>, dim3(g3), dim3(512), 0, s, a);
-                break;
-            case DCV_EPI_BIAS_RESID_F32:
-                if (!bias) return DCV_ERR_NULL;
-                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_BIAS_RESID_F32>, dim3(g3), dim3(512), 0, s, a);
-                break;
-            case DCV_EPI_PLAIN_BF16:
-                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_PLAIN_BF16>, dim3(g3), dim3(512), 0, s, a);
-                break;
-            case DCV_EPI_GELU_BWD_BF16:
-                if (!aux) return DCV_ERR_NULL;
-                hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_GELU_BWD_BF16>, dim3(g3), dim3(512), 0, s, a);
-                break;
+        if (g3 > cap) g3 = cap;
+        DCV_NT_CASES(gemm_nt384_kernel, g3)
             default:
                 return DCV_ERR_UNSUPPORTED;
         }
         DCV_LAUNCH_CHECK();
         return DCV_OK;
     }
-    a.queue = nt_queue_slot();
-    switch (epilogue) {
-        case DCV_EPI_BIAS_BF16:
-            if (!bias) return DCV_ERR_NULL;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_BF16>, dim3(grid), dim3(512), 0, s, a);
-            break;
-        case DCV_EPI_BIAS_GELU_BF16:
-            if (!bias || !out2) return DCV_ERR_NULL;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_GELU_BF16>, dim3(grid), dim3(512), 0, s, a);
-            break;
-        case DCV_EPI_BIAS_RESID_F32:
-            if (!bias) return DCV_ERR_NULL;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_BIAS_RESID_F32>, dim3(grid), dim3(512), 0, s, a);
-            break;
-        case DCV_EPI_PLAIN_BF16:
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_PLAIN_BF16>, dim3(grid), dim3(512), 0, s, a);
-            break;
-        case DCV_EPI_GELU_BWD_BF16:
-            if (!aux) return DCV_ERR_NULL;
-            hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_GELU_BWD_BF16>, dim3(grid), dim3(512), 0, s, a);
-            break;
+    int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
+    if (grid > cap) grid = cap;
+    DCV_NT_CASES(gemm_nt_kernel, grid)
         case DCV_EPI_PATCH:
             if (!bias || !aux || !aux2 || T <= 0 || n <= 0 || (M % T) != 0 || (T % n) != 0) return DCV_ERR_SHAPE;
             hipLaunchKernelGGL(gemm_nt_kernel<DCV_EPI_PATCH>, dim3(grid), dim3(512), 0, s, a);
@@ -1077,18 +961,28 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
+#undef DCV_NT_CASES
 
-extern "C" int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,
-                               float* dbias, void* stream) {
+extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue,
+                           const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
+                           const float* aux2, int T, int n, void* stream) {
+    return dcv_gemm_nt_ex(A, lda, W, ldw, M, N, K, epilogue, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n, 0, DCV_TILE_AUTO, stream);
+}
+
+extern "C" int dcv_gemm_tn_acc_ex(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,
+                                  float* dbias, int tile, void* stream) {
     if (!Y || !X || !dW) return DCV_ERR_NULL;
     if (M <= 0 || P <= 0 || Q <= 0 || (P % 8) || (Q % 8)) return DCV_ERR_SHAPE;
     if ((ldy % 8) || (ldx % 8) || ((uintptr_t)Y & 15) || ((uintptr_t)X & 15)) return DCV_ERR_ALIGN;
+    if (tile < DCV_TILE_AUTO || tile > DCV_TILE_WIDE) return DCV_ERR_SHAPE;
+    const int cus = dcv_cu_count();
     // measured (M = 100 416): 1152x384 158 -> 140 us, 1536x384 206 -> 176, 384x1536 203 -> 182, but 384x384 63 -> 79
     // (3 tiles x 85 splits: the fp32 atomic traffic grows faster than the operand traffic shrinks)
-    const char* small_env = getenv("DCV_TN_SMALL_TILE");
-    if ((P % 384) == 0 && (Q % 128) == 0 && (P / 384) * (Q / 128) >= 6 && !(small_env && small_env[0])) {
+    const int pick = dcv_gemm_tn_pick(M, P, Q, tile);
+    if (pick < 0) return pick;
+    if (pick == DCV_TILE_WIDE) {
         const int tiles3 = (P / 384) * (Q / 128);
-        int splits3 = 256 / tiles3;  // one 128 KB workgroup per CU, one resident round
+        int splits3 = cus / tiles3;  // one 128 KB workgroup per CU, one resident round
         const int max3 = (M + T3_BK - 1) / T3_BK;
         if (splits3 > max3) splits3 = max3;
         if (splits3 < 1) splits3 = 1;
@@ -1100,9 +994,9 @@ extern "C" int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, i
         return DCV_OK;
     }
     const int tiles = ((P + 127) / 128) * ((Q + 127) / 128);
-    // one resident round: 2 workgroups per CU (64 KB LDS each) x 256 CUs = 512 slots; a 513th workgroup would run
+    // one resident round: 2 workgroups per CU (64 KB LDS each) = 2 x CUs slots; one workgroup more would run
     // alone in a second round and double the launch time.  Every split is a multiple of BK rows.
-    int splits = 512 / tiles;
+    int splits = 2 * cus / tiles;
     int max_splits = (M + BK - 1) / BK;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -1112,4 +1006,9 @@ extern "C" int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, i
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
+}
+
+extern "C" int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,
+                               float* dbias, void* stream) {
+    return dcv_gemm_tn_acc_ex(Y, ldy, X, ldx, M, P, Q, dW, lddw, dbias, DCV_TILE_AUTO, stream);
 }

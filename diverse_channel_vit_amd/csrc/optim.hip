@@ -180,6 +180,22 @@ extern "C" int dcv_adamw(float* p, const float* g, float* m, float* v, long n, f
     return DCV_OK;
 }
 
+static __global__ void adamw_hyper_kernel(float* hyper, float lr, float b1, float b2, float eps, float wd, float inv_bc1, float inv_sqrt_bc2,
+                                   float gscale) {
+    hyper[0] = lr; hyper[1] = b1; hyper[2] = b2; hyper[3] = eps; hyper[4] = wd; hyper[5] = inv_bc1; hyper[6] = inv_sqrt_bc2; hyper[7] = gscale;
+}
+
+extern "C" int dcv_adamw_set_hyper(float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                   float grad_scale, void* stream) {
+    if (!hyper_dev) return DCV_ERR_NULL;
+    if (step <= 0) return DCV_ERR_SHAPE;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adamw_hyper_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper_dev, lr, beta1, beta2, eps, weight_decay,
+                       (float)(1.0 / bc1), (float)(1.0 / sqrt(bc2)), grad_scale);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
 extern "C" int dcv_adamw_dyn(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, void* stream) {
     if (!p || !g || !m || !v || !hyper_dev) return DCV_ERR_NULL;
     if (n <= 0) return DCV_ERR_SHAPE;

@@ -204,9 +204,9 @@ class _EncoderFn(torch.autograd.Function):
        outputs: CLS feature after the final LayerNorm [B,D] f32, ortho statistics [B,2] f32."""
 
     @staticmethod
-    def forward(ctx, model, ch_idx_dev, C, want_ortho, keep, x, E, pos_tab, *params):
+    def forward(ctx, model, ch_idx_dev, C, want_ortho, keep, tok, x, E, pos_tab, *params):
         st = model._run_forward(x, ch_idx_dev, C, E, pos_tab, want_ortho, save=any(ctx.needs_input_grad), keep=keep,
-                                st_scale=model._cur_scale, st_shift=model._cur_shift)
+                                st_scale=model._cur_scale, st_shift=model._cur_shift, tok=tok)
         ctx.model = model
         ctx.st = st
         return st["feat"], st["stats"]
@@ -220,7 +220,7 @@ class _EncoderFn(torch.autograd.Function):
         dE, dpos, grads = model._run_backward(st, dfeat.contiguous(), dstats)
         st["consumed"] = True
         st.clear()
-        return (None, None, None, None, None, None, dE, dpos) + tuple(grads)
+        return (None, None, None, None, None, None, None, dE, dpos) + tuple(grads)
 
 
 class DiChaViT(nn.Module):
@@ -254,6 +254,7 @@ class DiChaViT(nn.Module):
         self._idx_cache: Dict = {}
         self.hcs_sampler = None  # optional callable(model, chunk_name, cur_channels) -> (picked ids, positions): pins the subset
         self._in_scale = self._in_shift = None  # optional per-global-channel input affine (set_input_normalisation)
+        self._cur_scale = self._cur_shift = None  # the affine rows of the channels used by the current forward
         # bf16 operand copies of the weights: stochastically rounded on training forwards (unbiased w.r.t. the fp32
         # master every step), round-to-nearest otherwise.  DCV_WEIGHT_ROUNDING=nearest turns it off.
         self.stochastic_weight_rounding = os.environ.get("DCV_WEIGHT_ROUNDING", "stochastic") != "nearest"
@@ -364,16 +365,49 @@ class DiChaViT(nn.Module):
         self._in_scale = 1.0 / (max_pixel_value * std)
         self._in_shift = -mean / std
 
-    def _index_tensor(self, values, dtype, device):
-        """Small index lists live on the device once (no host->device copy per step; graph-capture safe)."""
+    def _index_tensor(self, values, dtype, device, cache=True):
+        """Channel index lists live on the device once (no host->device copy per step; graph-capture safe).  Only the
+        channel lists are cached (a few dozen distinct tuples of <= in_chans entries; the cache is bounded); per-step random
+        lists (the dropout_tokens_hcs keep list, ~1.5k entries, new every step) are built as temporaries."""
+        if not cache:
+            return torch.tensor(list(values), dtype=dtype, device=device)
         key = (tuple(values), dtype, str(device))
         t = self._idx_cache.get(key)
         if t is None:
+            if len(self._idx_cache) >= 4096:
+                self._idx_cache.clear()
             t = torch.tensor(list(values), dtype=dtype, device=device)
             self._idx_cache[key] = t
         return t
 
-    def _sample_channels(self, chunk_name, cur_channels, channel_embed):
+    def _proj_cosine(self, x, cur_channels):
+        """Channel-by-channel cosine of the PROJECTED input, batch mean (hcs_sampling=lowest_cosine_prob_proj,
+        dichavit.py:156-161): x_sim[b,c] = the conv output of channel c flattened over (h w d), L2-normalised; returns the
+        [Cin,Cin] matrix mean_b <x_sim[b,c], x_sim[b,e]>.  Runs the tokeniser kernels (im2col + MFMA GEMM, fp32 accumulate)
+        on all Cin channels under no_grad, like the reference."""
+        fe = self.feature_extractor
+        pe = fe.patch_embed
+        B, Cin, Hi, Wi = x.shape
+        P, D = fe.patch_size, self.dim
+        n = (Hi // P) * (Wi // P)
+        dev = x.device
+        idx_all = self._index_tensor(range(Cin), torch.int32, dev)
+        sc = sh = None
+        if self._in_scale is not None:
+            gi = self._index_tensor(cur_channels, torch.int64, dev)
+            sc, sh = self._in_scale.to(dev)[gi].contiguous(), self._in_shift.to(dev)[gi].contiguous()
+        Xp = torch.empty(B * Cin * n, P * P, dtype=torch.bfloat16, device=dev)
+        hip.im2col(x, idx_all, Xp, B, Cin, Cin, Hi, Wi, P, scale=sc, shift=sh)
+        Y = torch.empty(B * Cin * n, D, dtype=torch.float32, device=dev)
+        scratch = torch.empty(B, Cin * n + 1, D, dtype=torch.float32, device=dev)
+        zE, zP = torch.zeros(Cin, D, device=dev), torch.zeros(n + 1, D, device=dev)
+        self._refresh_operand_copies(stochastic=False)
+        hip.gemm_nt(Xp, self._bf(pe.proj.weight), hip.EPI_PATCH, scratch, bias=pe.proj.bias, out2=Y, aux=zE, aux2=zP, T=Cin * n, n=n,
+                    ldo=D, ldo2=D, ldaux=D)
+        xs = F.normalize(Y.view(B, Cin, n * D), p=2, dim=-1)
+        return torch.einsum("bcd,bed->bce", xs, xs).mean(dim=0)
+
+    def _sample_channels(self, chunk_name, cur_channels, channel_embed, x=None):
         """HCS sampling (dichavit.py:127-216).  Returns (sampled global ids, their positions in the chunk)."""
         pe = self.feature_extractor.patch_embed
         cfg = self.cfg
@@ -392,14 +426,17 @@ class DiChaViT(nn.Module):
             with torch.no_grad():
                 anchor = random.randint(0, Cin - 1)  # :154
                 if mode.endswith("_proj"):
-                    raise ValueError(f"hcs_sampling='{mode}' (projection-space cosine) is not provided by the HIP path")
-                e = F.normalize(channel_embed.detach(), p=2, dim=-1)
-                cos = (e @ e.t())[anchor]  # :169-174
+                    if mode != "lowest_cosine_prob_proj":
+                        raise ValueError(f"Invalid hcs_sampling: '{mode}'")  # :206 (the only *_proj mode the reference accepts)
+                    cos = self._proj_cosine(x, cur_channels)[anchor]  # :156-161
+                else:
+                    e = F.normalize(channel_embed.detach(), p=2, dim=-1)
+                    cos = (e @ e.t())[anchor]  # :169-174
                 if mode == "lowest_cosine":
                     ind = torch.topk(cos, k=Cin_new, largest=False).indices.cpu().tolist()
                 elif mode == "highest_cosine":
                     ind = torch.topk(cos, k=Cin_new, largest=True).indices.cpu().tolist()
-                elif mode == "lowest_cosine_prob":
+                elif mode in ("lowest_cosine_prob", "lowest_cosine_prob_proj"):
                     prob = F.softmax((1 - cos) / cfg.hcs_sampling_temp, dim=-1)  # :194-196
                     ind = torch.multinomial(prob, Cin_new, replacement=False).cpu().tolist()  # :199
                 else:
@@ -468,11 +505,14 @@ class DiChaViT(nn.Module):
         return torch.cat(rows, dim=0)
 
     def _pos_table(self, C, n_cur, H, W):
-        """[1+n_cur, D] table added to the tokens of every channel (dichavit.py:518-552)."""
+        """[1+n_cur, D] table added to the tokens of every channel (dichavit.py:518-552).  When the TOTAL token count C*n_cur
+        happens to equal the model's own grid size (C == 1 at the native resolution; or e.g. 4 channels at half the native
+        resolution) the reference takes its early-out (:529-530) and adds pos_embed[1+t] to token t ACROSS the channels: the
+        raw [1+C*n_cur, D] table is returned and the caller switches the tokeniser to per-token rows (forward())."""
         fe = self.feature_extractor
         pos = fe.pos_embed
         n_pos = pos.shape[1] - 1
-        if C * n_cur == n_pos and H == W:  # :529-530 (only reachable with C == 1)
+        if C * n_cur == n_pos and H == W:  # :529-530
             return pos[0]
         P = fe.patch_size
         g = int(math.sqrt(n_pos))
@@ -491,7 +531,7 @@ class DiChaViT(nn.Module):
     # ---------------------------------------------------------------------------------------
     # forward / backward drivers (kernel sequences)
     # ---------------------------------------------------------------------------------------
-    def _run_forward(self, x, ch_idx_dev, C, E, pos_tab, want_ortho, save, keep=None, st_scale=None, st_shift=None):
+    def _run_forward(self, x, ch_idx_dev, C, E, pos_tab, want_ortho, save, keep=None, st_scale=None, st_shift=None, tok=None):
         fe = self.feature_extractor
         D, H = self.dim, fe.num_heads
         P = fe.patch_size
@@ -503,14 +543,17 @@ class DiChaViT(nn.Module):
         bf, f32 = torch.bfloat16, torch.float32
         self._refresh_operand_copies(stochastic=bool(save) and self.training and self.stochastic_weight_rounding)
         pe = fe.patch_embed
-        st = dict(B=B, C=C, n=n, N=N, M=M, save=save)
+        # (channels, positions) structure of the embedding rows the tokeniser epilogue adds: (C, n) normally, (1, C*n) when the
+        # positional table is per token (the reference's early-out, _pos_table)
+        Ctok, ntok = tok if tok is not None else (C, n)
+        st = dict(B=B, C=C, n=n, N=N, M=M, save=save, tok=(Ctok, ntok))
         # --- tokeniser: im2col -> MFMA GEMM with (+bias +channel_embed[c] +pos[i]) epilogue ---
         Xp = torch.empty(B * T, P * P, dtype=bf, device=dev)
         hip.im2col(x, ch_idx_dev, Xp, B, Ct, C, Hi, Wi, P, scale=st_scale, shift=st_shift)
         xs = torch.empty(B, N, D, dtype=f32, device=dev)
         Y = torch.empty(B * T, D, dtype=f32, device=dev) if want_ortho else None
         Ec, pc = E.contiguous(), pos_tab.contiguous()
-        hip.gemm_nt(Xp, self._bf(pe.proj.weight), hip.EPI_PATCH, xs, bias=pe.proj.bias, out2=Y, aux=Ec, aux2=pc, T=T, n=n,
+        hip.gemm_nt(Xp, self._bf(pe.proj.weight), hip.EPI_PATCH, xs, bias=pe.proj.bias, out2=Y, aux=Ec, aux2=pc, T=T, n=ntok,
                     ldo=D, ldo2=D, ldaux=D)
         hip.fill_cls(xs, fe.cls_token, pc, B, N * D, D)
         stats = torch.zeros(B, 2, dtype=f32, device=dev)
@@ -525,7 +568,7 @@ class DiChaViT(nn.Module):
         if save:
             st["Xp"] = Xp
         if keep is not None:  # dropout_tokens_hcs: the encoder sees only the kept token rows (CLS first)
-            keep_dev = self._index_tensor(keep, torch.int32, dev)
+            keep_dev = self._index_tensor(keep, torch.int32, dev, cache=False)
             Nk = len(keep)
             xk = torch.empty(B, Nk, D, dtype=f32, device=dev)
             hip.gather_tokens(xs, keep_dev, xk, B, N, Nk, D)
@@ -601,25 +644,25 @@ class DiChaViT(nn.Module):
         # (read from librccl's gfx950 code object).  Neither NT GEMM kernel can share a CU with one (144 KB / 160 KB of the 160),
         # and both deal their tiles statically to one workgroup per CU, so a workgroup whose CU is taken starts late and the
         # whole GEMM waits for it (tools/hog_probe.py: 113 -> 190 us with 8 CU slots taken).  While collectives can be in
-        # flight the backward therefore (a) stays on the 256 x 128 kernel and (b) launches 8 workgroups fewer than there are CUs
-        # — dp.DataParallel asks RCCL for at most 8 channels — so that every workgroup finds a free CU at once.  Both knobs are
-        # read per GEMM call; the forward, where nothing else runs, keeps the wide tiles and the full grid.
-        saved = {k: os.environ.get(k) for k in ("DCV_NT384", "DCV_NT_GRID")}
-        guard = dp is not None and (dp.world > 1 or dp._force)
-        if guard:
-            if saved["DCV_NT384"] is None:
-                os.environ["DCV_NT384"] = "0"
-            if saved["DCV_NT_GRID"] is None:
-                os.environ["DCV_NT_GRID"] = str(256 - dp.reserved_cus)
-        try:
-            return self._run_backward_body(st, dfeat, dstats, ga, g, dp)
-        finally:
-            if guard:
-                for k, v in saved.items():
-                    if v is None:
-                        os.environ.pop(k, None)
+        # flight the backward therefore (a) stays on the 256 x 128 kernel and (b) launches `reserved_cus` workgroups fewer than
+        # there are CUs — dp.DataParallel asks RCCL for at most that many channels — so that every workgroup finds a free CU at
+        # once.  Both are explicit arguments of dcv_gemm_nt_ex; the forward, where nothing else runs, keeps the wide tiles and
+        # the full grid.
+        nt_kw = {}
+        if dp is not None and (dp.world > 1 or dp._force):
+            cus = torch.cuda.get_device_properties(dfeat.device).multi_processor_count if dfeat.is_cuda else 256
+            nt_kw = dict(grid_cap=max(cus - dp.reserved_cus, 1), tile=hip.TILE_NARROW)
+        if dp is not None:
+            dp.queue_finalize()  # the backward is self-synchronising: whatever follows loss.backward() sees reduced gradients
+        accumulating = dp is not None and any(p.grad is not None for p in (self._enc_params[0], self._enc_params[2], self._enc_params[-1]))
+        out = self._run_backward_body(st, dfeat, dstats, ga, g, dp, nt_kw)
+        if accumulating:
+            # a second backward pass of the same optimiser step (trainer.py:846-935): autograd is about to ADD these slices to
+            # .grad on the compute stream, so their all-reduces must have completed — wait here, inside the node
+            dp.finalize()
+        return out
 
-    def _run_backward_body(self, st, dfeat, dstats, ga, g, dp):
+    def _run_backward_body(self, st, dfeat, dstats, ga, g, dp, nt_kw):
         fe = self.feature_extractor
         D, H = self.dim, fe.num_heads
         B, C, n, N, M = st["B"], st["C"], st["n"], st["N"], st["M"]
@@ -648,15 +691,15 @@ class DiChaViT(nn.Module):
             R = B if tail else M
             dz_, du_ = (dz[:R], du[:R]) if tail else (dz, du)
             # MLP
-            hip.gemm_nt(dxb, self._bf(blk.mlp.fc2.weight, True), hip.EPI_GELU_BWD_BF16, dz_, aux=L["z"])
+            hip.gemm_nt(dxb, self._bf(blk.mlp.fc2.weight, True), hip.EPI_GELU_BWD_BF16, dz_, aux=L["z"], **nt_kw)
             hip.gemm_tn_acc(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias))
-            hip.gemm_nt(dz_, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du_)
+            hip.gemm_nt(dz_, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du_, **nt_kw)
             hip.gemm_tn_acc(dz_, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias))
             hip.ln_bwd(du_, L["x_mid"], L["mean2"], L["rstd2"], blk.norm2.weight, dx, dx, dxb, g(blk.norm2.weight), g(blk.norm2.bias), R, D)
             # attention
             if tail:
                 dO_c = du[B:2 * B]  # scratch rows of the same buffer
-                hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO_c)
+                hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO_c, **nt_kw)
                 hip.gemm_tn_acc(dxb, L["o_c"], g(blk.attn.proj.weight), g(blk.attn.proj.bias))
                 dO.view(B, N, D)[:, 0].copy_(dO_c)  # only the CLS rows of dO are read (nq = 1)
                 hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale, nq=1)
@@ -665,10 +708,10 @@ class DiChaViT(nn.Module):
                 dx.view(B, N, D)[:, 0].copy_(dx_c)
                 dxb = torch.empty(M, D, dtype=bf, device=dev)
             else:
-                hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO)
+                hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO, **nt_kw)
                 hip.gemm_tn_acc(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias))
                 hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
-            hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du)
+            hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du, **nt_kw)
             hip.gemm_tn_acc(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias))
             hip.ln_bwd(du, L["x_in"], L["mean1"], L["rstd1"], blk.norm1.weight, dx, dx, dxb, g(blk.norm1.weight), g(blk.norm1.bias), M, D)
             L.clear()
@@ -686,9 +729,10 @@ class DiChaViT(nn.Module):
             dYl = torch.empty(B * T, D, dtype=f32, device=dev)
             hip.ortho_bwd(st["Y"], st["S"], st["tot"], st["inv"], dstats.contiguous(), dYl, B, C, n, D)
         dYb = torch.empty(B * T, D, dtype=bf, device=dev)
-        dE = torch.zeros(C, D, dtype=f32, device=dev)
-        dpos = torch.zeros(n + 1, D, dtype=f32, device=dev)
-        hip.patch_bwd(dx, dYl, dYb, dE, dpos, g(fe.cls_token), B, C, n, D)
+        Ctok, ntok = st["tok"]
+        dE = torch.zeros(Ctok, D, dtype=f32, device=dev)
+        dpos = torch.zeros(ntok + 1, D, dtype=f32, device=dev)
+        hip.patch_bwd(dx, dYl, dYb, dE, dpos, g(fe.cls_token), B, Ctok, ntok, D)
         hip.gemm_tn_acc(dYb, st["Xp"], g(pe.proj.weight), g(pe.proj.bias))
         if dp is not None:
             dp.grad_ready(ga, *self._range_of([fe.cls_token, pe.proj.bias]))
@@ -727,7 +771,7 @@ class DiChaViT(nn.Module):
         channel_embed = pe.channel_embed(ch_t)  # [Cin, D]  :122
         idx = list(range(Cin))
         if self.training and pe.enable_sample:  # :127
-            cur_channels, idx = self._sample_channels(chunk_name, cur_channels, channel_embed)
+            cur_channels, idx = self._sample_channels(chunk_name, cur_channels, channel_embed, x)
             channel_embed = channel_embed[idx]  # :136/212
         if (not self.training) and (training_chunks is not None):  # :219
             channel_embed = self._eval_channel_embed(chunk_name, training_chunks, new_channel_init)
@@ -742,10 +786,20 @@ class DiChaViT(nn.Module):
         keep = self._token_keep(C, n)
         self._cur_scale = self._cur_shift = None
         if self._in_scale is not None:  # gather the affine like channel_embed: by the global ids of the channels used
+            if self._in_scale.device != x.device:  # moved to the device once (no pageable copy per step; capture-safe)
+                self._in_scale, self._in_shift = self._in_scale.to(x.device), self._in_shift.to(x.device)
             gi = self._index_tensor(cur_channels, torch.int64, x.device)
-            self._cur_scale = self._in_scale.to(x.device)[gi].contiguous()
-            self._cur_shift = self._in_shift.to(x.device)[gi].contiguous()
-        feat, stats = _EncoderFn.apply(self, ch_idx_dev, C, want_ortho, keep, x, channel_embed, pos_tab, *self._enc_params)
+            self._cur_scale = self._in_scale[gi].contiguous()
+            self._cur_shift = self._in_shift[gi].contiguous()
+        tok, E_tok = None, channel_embed
+        if C > 1 and pos_tab.shape[0] == 1 + C * n:
+            # the reference's early-out hit with several channels: token t gets pos_embed[1+t] whatever its channel.  The
+            # tokeniser epilogue adds aux[c(t)] + aux2[1 + i(t)]; with ONE pseudo-channel of C*n positions that is row 1+t of a
+            # per-token table into which the channel embeddings are folded (autograd routes the table's gradient back to both)
+            pos_tab = pos_tab + torch.cat([torch.zeros_like(channel_embed[:1]), channel_embed.repeat_interleave(n, dim=0)], dim=0)
+            E_tok = torch.zeros_like(channel_embed[:1])
+            tok = (1, C * n)
+        feat, stats = _EncoderFn.apply(self, ch_idx_dev, C, want_ortho, keep, tok, x, E_tok, pos_tab, *self._enc_params)
         # --- regularisers (tiny tensors; models/loss_fn.py) ---
         extra = 0
         if want_ortho:

@@ -7,8 +7,14 @@ layer first.  As soon as a layer's slice is complete the model calls ``grad_read
 and the slice is all-reduced asynchronously on RCCL's stream while the backward of the earlier
 layers keeps the compute stream busy (14 contiguous buckets of <= 7 MB for DiChaViT-S; no gather /
 scatter copies, no per-parameter hooks).  The few small parameters outside the encoder node (head,
-channel embeddings, positional table) are reduced from post-accumulate hooks.  ``finalize()`` makes
-the compute stream wait for every outstanding bucket; HipAdamW calls it before the update.
+channel embeddings, positional table) are reduced from post-accumulate hooks.
+
+The backward is SELF-SYNCHRONISING (as torch DDP's is): the model queues ``finalize()`` as an
+end-of-backward callback of the autograd engine, so whatever runs after ``loss.backward()`` — HipAdamW,
+torch/timm AdamW, ``torch.nn.utils.clip_grad_norm_``, ``scaler.unscale_`` — sees fully reduced gradients.
+With gradient accumulation (several backward passes per optimiser step, the CHAMMI step of
+trainer.py:846-935) the second and later passes wait for their own buckets before autograd adds them to
+``.grad``; the sum of per-pass averages equals the average of the sums.
 
 Parameters that received no gradient this step (``proxies`` in cross-entropy mode, dichavit.py:803-805)
 take no part — the reference needs ``find_unused_parameters=True`` for the same reason.
@@ -16,6 +22,8 @@ Ranks must draw the same HCS channel subset (same seed on every rank, SURVEY §5
 then match and the step stays balanced."""
 from __future__ import annotations
 
+import os
+import re
 from typing import List, Optional
 
 import torch
@@ -31,24 +39,50 @@ class DataParallel:
         """Call BEFORE torch.distributed.init_process_group: caps RCCL at `n` channels (= workgroups = CUs held during an
         all-reduce) unless the user already chose.  86 MB of gradients per ~40 ms step need a small fraction of the xGMI
         bandwidth, while every CU RCCL holds stalls a persistent GEMM workgroup."""
-        import os
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
         os.environ.setdefault("NCCL_MIN_NCHANNELS", str(min(n, 4)))
 
-    def __init__(self, model, process_group=None, min_bucket_bytes: int = 4 << 20, force_collectives: bool = False):
+    @staticmethod
+    def rccl_channels_from_log(path: str) -> Optional[int]:
+        """Number of channels RCCL actually set up, parsed from an ``NCCL_DEBUG=INFO`` log (``NCCL_DEBUG_FILE``): the
+        ``Channel 03/08 :`` ring lines or the ``N coll channels`` summary.  None when the log has neither."""
+        try:
+            with open(path, errors="replace") as f:
+                txt = f.read()
+        except OSError:
+            return None
+        m = re.findall(r"(\d+) coll channels", txt)
+        if m:
+            return int(m[-1])
+        m = re.findall(r"Channel \d+/(\d+)\s*:", txt)
+        if m:
+            return int(m[-1])
+        return None
+
+    def __init__(self, model, process_group=None, min_bucket_bytes: int = 4 << 20, force_collectives: bool = False,
+                 grad_dtype: torch.dtype = torch.float32, overlap: bool = True):
+        """grad_dtype=torch.bfloat16 exchanges a bf16 copy of every bucket (43 MB instead of 86 MB per step for DiChaViT-S;
+        the fp32 arena is overwritten with the averaged bf16 values).  overlap=False issues ONE all-reduce of everything
+        that became ready, after the backward (no collective runs beside the backward's kernels)."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
+        if grad_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype: float32 or bfloat16")
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.backend = dist.get_backend(process_group)
         self._avg = self.backend == "nccl"  # RCCL has a native AVG; gloo sums and we scale
         self._force = force_collectives     # issue the collectives even at world_size 1 (single-GPU plumbing tests)
-        self._works: List = []
-        self._scaled: List[torch.Tensor] = []
+        self._works: List = []              # (work or None, reduced buffer, fp32 destination or None)
         self._pending = None  # (arena, lo, hi) waiting to be merged into a bucket of >= min_bucket_bytes
+        self._deferred: List[torch.Tensor] = []  # overlap=False: slices waiting for finalize()
         self.min_bucket = min_bucket_bytes // 4
+        self.grad_dtype = grad_dtype
+        self.overlap = overlap
         self.buckets_launched = 0
+        self.bytes_reduced = 0
+        self._callback_queued = False
         model._dp = self
         self._hooks = []
         self._hooked = set()
@@ -74,44 +108,101 @@ class DataParallel:
     def _reduce(self, t: torch.Tensor) -> None:
         if self.world == 1 and not self._force:
             return
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
-        if not self._avg:
-            self._scaled.append(t)
+        if not self.overlap:
+            self._deferred.append(t)
+            return
+        self._all_reduce(t)
+
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        buf, dst = t, None
+        if self.grad_dtype != t.dtype:
+            buf, dst = t.to(self.grad_dtype), t  # bf16 copy travels; the average is written back in finalize()
+        if self.backend == "gloo" and buf.is_cuda:
+            # gloo (tests on a one-GPU box) reduces host memory: stage through the CPU, synchronously
+            h = buf.float().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h.mul_(1.0 / self.world))
+        else:
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+            self._works.append((w, buf, dst))
         self.buckets_launched += 1
+        self.bytes_reduced += buf.numel() * buf.element_size()
 
     def flush(self) -> None:
         """End of the encoder backward: launch whatever is still being merged."""
         self._launch_pending()
 
+    def queue_finalize(self) -> None:
+        """Called from inside a backward pass (the model's autograd node, the parameter hooks): finalize() runs when the
+        autograd engine has finished this pass, before ``loss.backward()`` returns to the caller."""
+        if self._callback_queued:
+            return
+        self._callback_queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(self._engine_callback)
+
+    def _engine_callback(self) -> None:
+        self._callback_queued = False
+        self.finalize()
+
     # ---- small parameters outside the encoder node --------------------------------------------------
     def hook_misc_params(self) -> None:
         """All-reduce the gradient of every parameter that is not part of the encoder arena as soon as
-        autograd has accumulated it."""
-        enc = {id(p) for p in getattr(self.model, "_enc_params", [])}
+        autograd has accumulated it.  Safe to call before the first forward (the arena need not exist yet)."""
+        enc = {id(p) for p in self.model._enc_param_list()}
         for p in self.model.parameters():
             if id(p) in enc or id(p) in self._hooked or not p.requires_grad:
                 continue
             self._hooked.add(id(p))
-            self._hooks.append(p.register_post_accumulate_grad_hook(lambda q: self._reduce(q.grad)))
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._misc_hook))
+
+    def _misc_hook(self, q) -> None:
+        # .grad holds the sum over this step's backward passes.  Reducing the whole of it in every pass is right: what
+        # earlier passes left there is already the rank average, which AVG (or SUM / world) maps onto itself.
+        self._reduce(q.grad)
+        self.queue_finalize()
+
+    def _wait_all(self) -> None:
+        for w, buf, dst in self._works:
+            w.wait()
+            if not self._avg:
+                buf.mul_(1.0 / self.world)
+            if dst is not None:
+                dst.copy_(buf)
+        self._works.clear()
 
     def finalize(self) -> None:
-        """Make the current stream wait for every outstanding all-reduce (call before optimizer.step)."""
+        """Make the current stream wait for every outstanding all-reduce.  Runs by itself at the end of every backward
+        pass (queue_finalize); HipAdamW.step and clip_grad_norm_ call it too (idempotent)."""
         self.flush()
-        for w in self._works:
-            w.wait()
-        self._works.clear()
-        if self._scaled:
-            inv = 1.0 / self.world
-            for t in self._scaled:
-                t.mul_(inv)
-            self._scaled.clear()
+        if self._deferred:
+            ts, self._deferred = self._deferred, []
+            # one collective over everything that became ready (contiguous arena slices are coalesced by torch)
+            flat = torch.cat([t.reshape(-1) for t in ts]) if len(ts) > 1 else ts[0].reshape(-1)
+            self._all_reduce(flat)
+            self._wait_all()
+            if len(ts) > 1:
+                o = 0
+                for t in ts:
+                    t.copy_(flat[o:o + t.numel()].view_as(t))
+                    o += t.numel()
+        self._wait_all()
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Same initial weights on every rank (DDP does this in its constructor)."""
         arena = getattr(self.model, "_arena", None)
         if arena is not None:
-            dist.broadcast(arena, src=src, group=self.group)
+            if self.backend == "gloo" and arena.is_cuda:
+                h = arena.cpu()
+                dist.broadcast(h, src=src, group=self.group)
+                arena.copy_(h)
+            else:
+                dist.broadcast(arena, src=src, group=self.group)
         else:
             for p in self.model.parameters():
-                dist.broadcast(p.data, src=src, group=self.group)
+                if self.backend == "gloo" and p.is_cuda:
+                    h = p.data.cpu()
+                    dist.broadcast(h, src=src, group=self.group)
+                    p.data.copy_(h)
+                else:
+                    dist.broadcast(p.data, src=src, group=self.group)

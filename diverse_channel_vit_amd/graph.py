@@ -22,6 +22,9 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep needs HipAdamW(capturable=True)")
         if model.training and model.feature_extractor.patch_embed.enable_sample and model.hcs_sampler is None:
             raise ValueError("HCS sampling changes the sequence length every step: pin it (model.hcs_sampler) or run eager")
+        if model.training and (model.cfg.get("dropout_tokens_hcs", "none") if hasattr(model.cfg, "get") else "none") not in (None, "none"):
+            raise ValueError("dropout_tokens_hcs draws a new token subset every step from the python RNG: a captured step would "
+                             "replay the subset drawn at capture time — run eager")
         self.model, self.opt = model, optimizer
         self.chunk_name, self.training_chunks = chunk_name, training_chunks
         self.loss_fn = loss_fn or torch.nn.CrossEntropyLoss()

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCV_LIB", os.path.join(_HERE, "libdcv_hip.so"))  # DCV_LIB: A/B builds of the same ABI
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RESID_F32, EPI_PLAIN_BF16, EPI_GELU_BWD_BF16, EPI_PATCH = range(6)
+TILE_AUTO, TILE_NARROW, TILE_WIDE = range(3)  # include/dcv.h DCV_TILE_*
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
@@ -20,7 +21,11 @@ _SIGS = {
     "dcv_debug_hog": ([_i, _i, _i, _vp], _i),
     "dcv_error_string": ([_i], C.c_char_p),
     "dcv_gemm_nt": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp], _i),
+    "dcv_gemm_nt_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp], _i),
+    "dcv_gemm_nt_pick": ([_i, _i, _i, _i, _i], _i),
+    "dcv_gemm_tn_pick": ([_i, _i, _i, _i], _i),
     "dcv_gemm_tn_acc": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp], _i),
+    "dcv_gemm_tn_acc_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp], _i),
     "dcv_ln_fwd": ([_vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp], _i),
     "dcv_ln_bwd": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp], _i),
     "dcv_attn_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
@@ -40,6 +45,7 @@ _SIGS = {
     "dcv_ortho_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_adamw": ([_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
     "dcv_adamw_dyn": ([_vp, _vp, _vp, _vp, _l, _vp, _vp], _i),
+    "dcv_adamw_set_hyper": ([_vp, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
     "dcv_cast_bf16": ([_vp, _vp, _l, _vp], _i),
     "dcv_cast_transpose_bf16": ([_vp, _vp, _vp, _i, _i, _vp], _i),
     "dcv_sumsq_acc": ([_vp, _l, _vp, _vp], _i),
@@ -68,21 +74,28 @@ def load() -> C.CDLL:
     return _lib
 
 
-# optional per-entry timing with events on the launch stream (bench.py): {name: [(start, end), ...]}
-_prof = None
+# optional per-kernel timing with events on the launch stream (bench.py).  Records are keyed by the device SYMBOL the entry
+# launches plus its problem shape, e.g. ("gemm_nt384_kernel<1>", "M100416 N1536 K384"); every record carries the algorithmic
+# and the executed FLOPs and the algorithmic HBM bytes of that launch.
+_prof = None          # None | {key: {"ev": [(start, end)], "flops": f, "flops_exec": f, "bytes": b}}
+_prof_only = None     # None | set of symbols to time (everything when None)
 
 
-def set_profiler(names=None):
-    """names: iterable of entry names to time (None disables).  Returns the previous records."""
-    global _prof
+def set_profiler(enable=False, only=None):
+    """enable: start a fresh record set (False/None disables).  only: iterable of symbols to time.  Returns the previous records."""
+    global _prof, _prof_only
     old = _prof
-    _prof = None if names is None else {n: [] for n in names}
+    _prof = {} if enable else None
+    _prof_only = None if only is None else set(only)
     return old
 
 
 class _timed:
-    def __init__(self, name):
-        self.rec = None if _prof is None else _prof.get(name)
+    def __init__(self, symbol, shape="", flops=0.0, flops_exec=None, nbytes=0.0):
+        self.rec = None
+        if _prof is not None and (_prof_only is None or symbol in _prof_only):
+            self.rec = _prof.setdefault((symbol, shape), {"ev": [], "flops": float(flops), "flops_exec": float(flops if flops_exec is None else flops_exec),
+                                                          "bytes": float(nbytes)})
 
     def __enter__(self):
         if self.rec is not None:
@@ -93,7 +106,29 @@ class _timed:
         if self.rec is not None:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            self.rec.append((self.s, e))
+            self.rec["ev"].append((self.s, e))
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _Null()
+
+
+def _timer(describe):
+    """describe() -> (symbol, shape, flops, flops_exec, bytes); evaluated only while profiling (no host cost otherwise)."""
+    if _prof is None:
+        return _NULL
+    return _timed(*describe())
+
+
+_EPI_OUT_BYTES = {0: 2, 1: 4, 2: 4, 3: 2, 4: 2, 5: 8}   # bytes written per output element (GELU: two bf16; PATCH: tokens + pre-embedding copy)
+_EPI_AUX_BYTES = {0: 0, 1: 0, 2: 4, 3: 0, 4: 2, 5: 0}   # bytes read per output element besides the operands (residual f32, saved GELU' bf16)
 
 
 def _check(rc: int, what: str) -> None:
@@ -119,8 +154,9 @@ def _req(t: torch.Tensor, dtype, name: str):
 
 
 # ---------------------------------------------------------------------------------------------
-def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T=0, n=0, ldo=None, ldo2=None, ldaux=None):
-    """C = A[M,K] @ W[N,K]^T with the given epilogue (see include/dcv.h)."""
+def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T=0, n=0, ldo=None, ldo2=None, ldaux=None,
+            grid_cap=0, tile=TILE_AUTO):
+    """C = A[M,K] @ W[N,K]^T with the given epilogue (see include/dcv.h).  grid_cap / tile: dcv_gemm_nt_ex's launch controls."""
     _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W")
     M, K = A.shape
     N = W.shape[0]
@@ -128,32 +164,43 @@ def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T
     ldo = out.shape[-1] if ldo is None else ldo
     ldo2 = (out2.shape[-1] if out2 is not None else 0) if ldo2 is None else ldo2
     ldaux = (aux.shape[-1] if aux is not None else 0) if ldaux is None else ldaux
-    with _timed("gemm_nt"):
-        rc = load().dcv_gemm_nt(_p(A), K, _p(W), K, M, N, K, epilogue, _p(bias), _p(out), ldo, _p(out2), ldo2, _p(aux), ldaux,
-                                _p(aux2), T, n, _stream())
+    lib = load()
+
+    def describe():
+        wide = lib.dcv_gemm_nt_pick(M, N, K, epilogue, tile) == TILE_WIDE
+        nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (_EPI_OUT_BYTES[epilogue] + _EPI_AUX_BYTES[epilogue])
+        return f"gemm_nt{'384' if wide else ''}_kernel<{epilogue}>", f"M{M} N{N} K{K}", 2.0 * M * N * K, None, nbytes
+
+    with _timer(describe):
+        rc = lib.dcv_gemm_nt_ex(_p(A), K, _p(W), K, M, N, K, epilogue, _p(bias), _p(out), ldo, _p(out2), ldo2, _p(aux), ldaux,
+                                   _p(aux2), T, n, grid_cap, tile, _stream())
     _check(rc, "dcv_gemm_nt")
 
 
-def gemm_tn_acc(Y, X, dW, dbias=None):
+def gemm_tn_acc(Y, X, dW, dbias=None, tile=TILE_AUTO):
     """dW[P,Q] += Y[M,P]^T @ X[M,Q]; dbias[P] += colsum(Y)."""
     _req(Y, torch.bfloat16, "Y"); _req(X, torch.bfloat16, "X"); _req(dW, torch.float32, "dW")
     M, P = Y.shape
     Q = X.shape[1]
     assert X.shape[0] == M and dW.numel() == P * Q
-    with _timed("gemm_tn"):
-        rc = load().dcv_gemm_tn_acc(_p(Y), P, _p(X), Q, M, P, Q, _p(dW), Q, _p(dbias), _stream())
+    lib = load()
+    with _timer(lambda: ("gemm_tn384_kernel" if lib.dcv_gemm_tn_pick(M, P, Q, tile) == TILE_WIDE else "gemm_tn_kernel", f"M{M} P{P} Q{Q}",
+                         2.0 * M * P * Q, None, 2.0 * M * (P + Q) + 8.0 * P * Q)):
+        rc = lib.dcv_gemm_tn_acc_ex(_p(Y), P, _p(X), Q, M, P, Q, _p(dW), Q, _p(dbias), tile, _stream())
     _check(rc, "dcv_gemm_tn_acc")
 
 
 def ln_fwd(x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride=None):
-    with _timed("ln_fwd"):
+    with _timer(lambda: (f"ln_fwd_kernel<{'true' if out.dtype == torch.float32 else 'false'}, {2 if D <= 512 else 4}>", f"M{M} D{D}", 0.0, None,
+                         M * D * (4.0 + (4.0 if out.dtype == torch.float32 else 2.0)))):
         rc = load().dcv_ln_fwd(_p(x), D if x_row_stride is None else x_row_stride, _p(gamma), _p(beta), _p(out),
                                1 if out.dtype == torch.float32 else 0, _p(mean), _p(rstd), M, D, eps, _stream())
     _check(rc, "dcv_ln_fwd")
 
 
 def ln_bwd(du, x, mean, rstd, gamma, dx_in, dx_out, dx_bf16, dgamma, dbeta, M, D, x_row_stride=None, dx_row_stride=None):
-    with _timed("ln_bwd"):
+    with _timer(lambda: (f"ln_bwd_kernel<{'true' if du.dtype == torch.float32 else 'false'}, {2 if D <= 512 else 4}>", f"M{M} D{D}", 0.0, None,
+                         M * D * ((4.0 if du.dtype == torch.float32 else 2.0) + 4.0 + (4.0 if dx_in is not None else 0.0) + 4.0 + (2.0 if dx_bf16 is not None else 0.0)))):
         rc = load().dcv_ln_bwd(_p(du), 1 if du.dtype == torch.float32 else 0, _p(x), D if x_row_stride is None else x_row_stride,
                                _p(mean), _p(rstd), _p(gamma), _p(dx_in), _p(dx_out), D if dx_row_stride is None else dx_row_stride,
                                _p(dx_bf16), _p(dgamma), _p(dbeta), M, D, _stream())
@@ -162,7 +209,10 @@ def ln_bwd(du, x, mean, rstd, gamma, dx_in, dx_out, dx_bf16, dgamma, dbeta, M, D
 
 def attn_fwd(qkv, o, lse, B, N, H, hd, scale, nq=None):
     """nq: only the query rows [0, nq) of every (batch, head) are processed (default: all N)."""
-    with _timed("attn_fwd"):
+    nq_ = N if nq is None else nq
+    prod = 2.0 * B * H * nq_ * N * hd  # one (query rows) x N x head_dim product over all (batch, head) pairs
+    D_ = H * hd
+    with _timer(lambda: ("attn_fwd3_kernel", f"B{B} N{N} H{H} Nq{nq_}", 2 * prod, 2 * prod, 2.0 * B * (N * 2 * D_ + nq_ * 2 * D_) + 4.0 * B * H * nq_)):
         rc = load().dcv_attn_fwd_rows(_p(qkv), _p(o), _p(lse), B, N, N if nq is None else nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_fwd")
 
@@ -172,10 +222,14 @@ def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None):
     nq = N if nq is None else nq
     if delta_ws.numel() < 2 * B * H * N or delta_ws.dtype != torch.float32:
         raise ValueError("attention backward workspace: 2*B*H*N float32 (-delta, then lse*log2e)")
-    with _timed("attn_bwd_dq"):  # also writes the row statistics into the workspace
+    prod = 2.0 * B * H * nq * N * hd
+    D_ = H * hd
+    # algorithmic credit: the backward is 4 products (dP, dV, dK, dQ); the S recomputation is executed
+    # in both kernels but not credited: dQ kernel 1 credited / 3 executed, dK/dV kernel 3 credited / 4 executed
+    with _timer(lambda: ("attn_bwd_dq2_kernel", f"B{B} N{N} H{H} Nq{nq}", 1 * prod, 3 * prod, 2.0 * B * (N * 3 * D_ + nq * 3 * D_))):  # also writes the row statistics
         rc = lib.dcv_attn_bwd_dq_rows(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dq")
-    with _timed("attn_bwd_dkdv"):
+    with _timer(lambda: ("attn_bwd_dkdv2_kernel", f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 2 * D_ + N * 2 * D_))):
         rc = lib.dcv_attn_bwd_dkdv_rows(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dkdv")
 
@@ -214,6 +268,10 @@ def adamw(p, g, m, v, n, lr, b1, b2, eps, wd, step, grad_scale=1.0):
 
 def adamw_dyn(p, g, m, v, n, hyper_dev):
     _check(load().dcv_adamw_dyn(_p(p), _p(g), _p(m), _p(v), n, _p(hyper_dev), _stream()), "dcv_adamw_dyn")
+
+
+def adamw_set_hyper(hyper_dev, lr, b1, b2, eps, wd, step, grad_scale=1.0):
+    _check(load().dcv_adamw_set_hyper(_p(hyper_dev), lr, b1, b2, eps, wd, step, grad_scale, _stream()), "dcv_adamw_set_hyper")
 
 
 def cast_bf16(src, dst, n):

@@ -30,21 +30,17 @@ class HipAdamW(torch.optim.Optimizer):
         # rewrites before every step, so step() can live inside a captured HIP graph (graph.GraphedTrainStep)
         self.capturable = capturable
         self._hyper_dev = None
-        self._hyper_host = None
 
     def advance(self):
-        """capturable mode: bump the step count and upload this step's scalars (async, current stream)."""
-        import math
+        """capturable mode: bump the step count and hand this step's scalars to the device.  They travel BY VALUE as the
+        arguments of a one-thread kernel on the current stream (dcv_adamw_set_hyper): stream-ordered against the replays, and
+        there is no host staging buffer that a host running several steps ahead of the device could overwrite."""
         grp = self.param_groups[0]
         self._step += 1
         b1, b2 = grp["betas"]
-        vals = [float(grp["lr"]), b1, b2, float(grp["eps"]), float(grp["weight_decay"]),
-                1.0 / (1.0 - b1 ** self._step), 1.0 / math.sqrt(1.0 - b2 ** self._step), 1.0]
         if self._hyper_dev is None:
-            self._hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
             self._hyper_dev = torch.zeros(8, dtype=torch.float32, device=grp["params"][0].device)
-        self._hyper_host.copy_(torch.tensor(vals, dtype=torch.float32))
-        self._hyper_dev.copy_(self._hyper_host, non_blocking=True)
+        hip.adamw_set_hyper(self._hyper_dev, float(grp["lr"]), b1, b2, float(grp["eps"]), float(grp["weight_decay"]), self._step, 1.0)
 
     def _ensure_state(self):
         model = self.model

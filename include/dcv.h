@@ -7,8 +7,10 @@
  * replaces the ATen op sequence cited next to it.  INTEGRATION.md shows the ctypes binding.
  *
  * Conventions: every entry returns 0 or a negative DCV_ERR_* code; never throws, never allocates,
- * never synchronises; all buffers are device pointers owned by the caller; `stream` is a hipStream_t
- * (pass torch.cuda.current_stream().cuda_stream); entries are re-entrant (no global mutable state).
+ * never synchronises, never reads the environment; all buffers are device pointers owned by the caller;
+ * `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); entries are re-entrant and
+ * graph-capturable: the only process-wide state is a cache of each device's CU count
+ * (hipDeviceGetAttribute, read once per device).  Every tuning choice is an explicit argument (the *_ex forms).
  * bf16 buffers are raw 16-bit brain-float; "f32" is IEEE binary32.  Only gfx950 code is built.
  */
 #ifndef DCV_H
@@ -41,11 +43,28 @@ const char* dcv_error_string(int code);
 int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue, const float* bias,
                 void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux, const float* aux2, int T, int n,
                 void* stream);
+/* Tile variants of the *_ex forms.  gemm_nt: NARROW = 256 x 128 output tile, WIDE = 256 x 384 (needs N % 384 == 0, not the
+ * PATCH epilogue).  gemm_tn_acc: NARROW = 128 x 128, WIDE = 384 x 128 (needs P % 384 == 0, Q % 128 == 0).  AUTO picks by
+ * measured shape rules.  Forcing an illegal variant returns DCV_ERR_UNSUPPORTED. */
+#define DCV_TILE_AUTO 0
+#define DCV_TILE_NARROW 1
+#define DCV_TILE_WIDE 2
+/* dcv_gemm_nt with its launch controls as arguments: both kernels are persistent (one workgroup per CU walks the output
+ * tiles, several rounds when there are more tiles than workgroups); grid_cap > 0 caps the number of workgroups (0 = one per
+ * CU of the current device) — the data-parallel backward leaves CUs to RCCL's kernels this way. */
+int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue, const float* bias,
+                   void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux, const float* aux2, int T, int n,
+                   int grid_cap, int tile, void* stream);
 
 /* dW[P,Q] (f32) += sum_m Y[m,P] * X[m,Q] ; dbias[P] (f32, nullable) += sum_m Y[m,P].  bf16 inputs.
  * Replaces the weight/bias gradients of nn.Linear / Conv3d (autograd of vit.py:72-74,123,142; dichavit.py:377). */
 int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias,
                     void* stream);
+/* the variant (DCV_TILE_NARROW / DCV_TILE_WIDE) the *_ex forms launch for a problem — pure functions of their arguments */
+int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile);
+int dcv_gemm_tn_pick(int M, int P, int Q, int tile);
+int dcv_gemm_tn_acc_ex(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias,
+                       int tile, void* stream);
 
 /* LayerNorm (eps inside the sqrt, biased variance) — vit.py:361,374 / dichavit.py:651.
  * out is bf16 [M,D] (or f32 when out_is_f32); mean/rstd [M] may be NULL. x rows are x_row_stride floats apart. */
@@ -111,8 +130,13 @@ int dcv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, fl
               float weight_decay, int step, float grad_scale, void* stream);
 /* same update with the scalars read from device memory: hyper_dev[8] = {lr, beta1, beta2, eps, weight_decay,
  * 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale}.  Lets a captured HIP graph of the step be replayed while the
- * step count and the schedulers' lr / weight decay advance (the host rewrites the 32 bytes between replays). */
+ * step count and the schedulers' lr / weight decay advance (dcv_adamw_set_hyper rewrites the 32 bytes between replays). */
 int dcv_adamw_dyn(float* p, const float* g, float* m, float* v, long n, const float* hyper_dev, void* stream);
+/* writes hyper_dev[8] for step `step` (bias corrections computed in double on the host, passed BY VALUE to a one-thread
+ * kernel): stream-ordered, no host staging buffer, so a host that runs many steps ahead of the device cannot overwrite the
+ * scalars of a step that has not executed yet. */
+int dcv_adamw_set_hyper(float* hyper_dev, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                        float grad_scale, void* stream);
 /* Gradient clipping (trainer.py:1003-1004 -> torch.nn.utils.clip_grad_norm_, L2): dcv_sumsq_acc adds sum(x^2) of a flat fp32
  * range to the device scalar *acc (zero it first; call once per gradient buffer); dcv_clip_scale multiplies a range by
  * min(1, max_norm / (sqrt(*sumsq_dev) + 1e-6)).  Everything stays on the device: no host sync, graph-capturable. */

@@ -98,7 +98,7 @@ def pos_embed_for(pos_embed: Tensor, n_tokens_minus_cls: int, w_img: int, h_img:
     """interpolate_pos_encoding (models/dichavit.py:518-552).  pos_embed [1, 1+g*g, D].
     Returns [1, 1+nc*w0*h0, D]."""
     n_pos = pos_embed.shape[1] - 1
-    if n_tokens_minus_cls == n_pos and w_img == h_img:  # :529-530 (only when nc == 1)
+    if n_tokens_minus_cls == n_pos and w_img == h_img:  # :529-530 (nc == 1 at the native size; also nc > 1 when nc * n == n_pos)
         return pos_embed
     D = pos_embed.shape[-1]
     g = int(math.sqrt(n_pos))
@@ -321,23 +321,36 @@ def chammi_loss(sd, x, y, cfg, ch_ids, idx, extra_loss_lambda: float = 1.0):
 # --------------------------------------------------------------------------------------
 # HCS channel sampling (models/dichavit.py:127-216) — host side, RNG injectable
 # --------------------------------------------------------------------------------------
+def proj_cosine(sd: Dict[str, Tensor], x: Tensor, P: int) -> Tensor:
+    """Cosine of the PROJECTED input per channel pair, batch mean (hcs_sampling=*_proj, models/dichavit.py:156-161):
+    x_sim[b,c] = normalize(flatten_(h w d)(conv(x)[b,:,c])), cos[c,e] = mean_b <x_sim[b,c], x_sim[b,e]>."""
+    B, C = x.shape[:2]
+    Y = patch_tokens(sd, x, P)  # [B, C*n, D], token t = c*n + i
+    xs = F.normalize(Y.reshape(B, C, -1), p=2, dim=-1)
+    return torch.einsum("bcd,bed->bce", xs, xs).mean(dim=0)
+
+
 def hcs_sample(channel_embed_rows: Tensor, cur_channels: Sequence[int], mode: Optional[str], temp: float,
-               rng: _pyrandom.Random, multinomial=None) -> Tuple[List[int], List[int]]:
+               rng: _pyrandom.Random, multinomial=None, proj_cos: Optional[Tensor] = None) -> Tuple[List[int], List[int]]:
     """Returns (sampled global channel ids in sampled order, positions within cur_channels).
-    Draw order: randint(1,C) -> [randint(0,C-1) -> multinomial]."""
+    Draw order: randint(1,C) -> [randint(0,C-1) -> multinomial].
+    proj_cos: the [C,C] matrix of proj_cosine() for mode 'lowest_cosine_prob_proj'."""
     C = len(cur_channels)
     k = rng.randint(1, C)  # :128
     if mode in (None, "none"):
         picked = rng.sample(list(cur_channels), k=k)  # :131
         return picked, [list(cur_channels).index(c) for c in picked]
     anchor = rng.randint(0, C - 1)  # :154
-    e = F.normalize(channel_embed_rows.detach(), p=2, dim=-1)
-    cos = (e @ e.t())[anchor]  # :169-174
+    if mode is not None and mode.endswith("_proj"):
+        cos = proj_cos.detach()[anchor]  # :156-161
+    else:
+        e = F.normalize(channel_embed_rows.detach(), p=2, dim=-1)
+        cos = (e @ e.t())[anchor]  # :169-174
     if mode == "lowest_cosine":
         ind = torch.topk(cos, k=k, largest=False).indices.tolist()  # :177
     elif mode == "highest_cosine":
         ind = torch.topk(cos, k=k, largest=True).indices.tolist()  # :183
-    elif mode == "lowest_cosine_prob":
+    elif mode in ("lowest_cosine_prob", "lowest_cosine_prob_proj"):
         prob = F.softmax((1 - cos) / temp, dim=-1)  # :194-196
         ind = (multinomial or torch.multinomial)(prob, k, replacement=False).tolist()  # :199
     else:

@@ -405,8 +405,168 @@ def case_schedules(dichavit, loss_fn):
     save("schedules", meta, arrays)
 
 
+
+def case_chammi_hcs(dichavit, loss_fn):
+    """BASELINE config 3 as specified: CHAMMI 12-channel model WITH enable_sample=True (HCS on the NON-identity mapper:
+    global channel ids 3..6 / 7..11 differ from the positions inside the chunk's tensor; dichavit.py:120-136,
+    203-212, 399-402).  Two rounds over the three chunks with seeded RNGs; gradients accumulate over a round's chunks."""
+    cfg = base_cfg(patch_size=16, proxy_loss_lambda=0.1, ortho_loss_v1_lambda=1.0, gamma_s=0.5, gamma_d=2.0,
+                   enable_sample=True, hcs_sampling="lowest_cosine_prob", hcs_sampling_temp=0.1)
+    mapper = {"Allen": [0, 1, 2], "HPA": [3, 4, 5, 6], "CP": [7, 8, 9, 10, 11]}
+    K, img, seed = 14, 64, 53
+    model, keys = build(dichavit, cfg, mapper, 12, img, K, seed)
+    model.train()
+    pe = model.feature_extractor.patch_embed
+    arrays, draws = {}, []
+    k = 0
+    for rnd, (mode, temp) in enumerate([("lowest_cosine_prob", 0.1), ("lowest_cosine", 0.1)]):
+        model.cfg["hcs_sampling"], model.cfg["hcs_sampling_temp"] = mode, temp
+        model.zero_grad()
+        for chunk in ["Allen", "HPA", "CP"]:
+            C = len(mapper[chunk])
+            x, y = orc.make_batch(seed + 10 * rnd + C, 2, C, img, K)
+            pyseed, tseed = 100 + k, 200 + k
+            pe.counter.clear()
+            random.seed(pyseed)
+            torch.manual_seed(tseed)
+            feat, extra = model(x, chunk, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            loss = loss_fn.proxy_loss(model.proxies, feat, y, model.scale) + 1.0 * extra
+            loss.backward()
+            rng = random.Random(pyseed)
+            torch.manual_seed(tseed)
+            rows = pe.channel_embed.weight.detach()[mapper[chunk]]
+            picked, idx = orc.hcs_sample(rows, mapper[chunk], mode, temp, rng)
+            assert sorted(pe.counter.keys()) == sorted(set(picked)), (dict(pe.counter), picked)
+            arrays[f"d{k}_feat"] = feat.detach().numpy()
+            arrays[f"d{k}_extra"] = np.array(extra.item())
+            arrays[f"d{k}_loss"] = np.array(loss.item())
+            arrays[f"d{k}_picked"] = np.array(picked)
+            draws.append(dict(chunk=chunk, rnd=rnd, pyseed=pyseed, tseed=tseed, mode=mode, temp=temp, batch_seed=seed + 10 * rnd + C))
+            print(f"  chammi_hcs {k}: {chunk} mode={mode} picked={picked} (positions {idx}) loss={loss.item():.6f}")
+            k += 1
+        for name_, v in grad_summary(model).items():
+            arrays[f"r{rnd}/{name_}"] = v
+    save("chammi_hcs", dict(cfg=cfg, mapper=mapper, n_channels=12, img=img, num_classes=K, B=2, seed=seed, draws=draws), arrays)
+
+
+def case_jumpcp_b16(dichavit, loss_fn):
+    """Headline architecture at batch 16: M = 16 x 1569 = 25 104 token rows -> 297 output tiles on a 256-workgroup grid: the
+    persistent multi-round GEMM walk and the 256 x 384 kernel (M >= 4096) run inside a MODEL-level golden."""
+    _train_case(dichavit, "jumpcp_s_b16", base_cfg(), {"train": list(range(8))}, "train", 8, 8, 224, 161, 16, 35, stages=False)
+
+
+def case_base64(dichavit, loss_fn):
+    """BASELINE config 5 as a whole model: DiChaViT-Base, 64 channels, 224^2 -> N = 12 545 tokens, batch 1, forward only
+    (eval mode, bare logits).  The reference materialises 12 x 12 545^2 fp32 attention matrices (7.5 GB per layer)."""
+    cfg = base_cfg(pretrained_model_name="base")
+    mapper = {"train": list(range(64))}
+    model, keys = build(dichavit, cfg, mapper, 64, 224, 161, 111)
+    model.eval()
+    x, _ = orc.make_batch(112, 1, 64, 224, 161)
+    t = time.time()
+    with torch.inference_mode():
+        out = model(x, "train", None, init_first_layer=None, new_channel_init=None)
+    print(f"  base64: forward {time.time()-t:.1f}s logits[:4]={out[0, :4].tolist()}")
+    save("base64_fwd", dict(cfg=cfg, mapper=mapper, n_channels=64, img=224, num_classes=161, B=1, seed=111), dict(logits=out.numpy()))
+
+
+def case_resolution_quirk(dichavit, loss_fn):
+    """interpolate_pos_encoding's early-out (dichavit.py:529-530) hit with SEVERAL channels: a 32-px / P8 model (16 grid
+    positions) fed 16-px images with 4 channels has 4 x 4 = 16 patch tokens = the model's own count, and H == W: the raw
+    pos_embed is added token by token ACROSS the channels (no per-channel tiling, no resampling)."""
+    cfg = base_cfg(patch_size=8)
+    mapper = {"train": [0, 1, 2, 3]}
+    model, keys = build(dichavit, cfg, mapper, 4, 32, 6, 95)
+    model.train()
+    x, y = orc.make_batch(196, 2, 4, 16, 6)
+    out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+    loss.backward()
+    fe = model.feature_extractor
+    arrays = dict(logits=out.detach().numpy(), loss=np.array(loss.item()), extra=np.array(extra.item()),
+                  gpos=fe.pos_embed.grad.numpy().copy(), gchan=fe.patch_embed.channel_embed.weight.grad.numpy().copy(),
+                  gnorm_proj=np.array(fe.patch_embed.proj.weight.grad.norm().item()),
+                  gcls=fe.cls_token.grad.numpy().copy())
+    model.eval()
+    with torch.inference_mode():
+        arrays["eval"] = model(x, "train", None, new_channel_init=None).numpy()
+    print(f"  resolution quirk: loss={loss.item():.6f}")
+    save("resolution_quirk", dict(cfg=cfg, mapper=mapper, n_channels=4, img=32, img_in=16, num_classes=6, B=2, seed=95), arrays)
+
+
+def case_hcs_proj(dichavit, loss_fn):
+    """hcs_sampling=lowest_cosine_prob_proj (dichavit.py:156-161): cosine of the PROJECTED input, batch mean.  The fixture
+    holds the cosine matrix (computed with the reference's own proj module), the subset the reference drew under the seeds,
+    and the step's outputs."""
+    from einops import rearrange
+    cfg = base_cfg(patch_size=8, enable_sample=True, hcs_sampling="lowest_cosine_prob_proj", hcs_sampling_temp=0.05)
+    mapper = {"train": list(range(6))}
+    model, keys = build(dichavit, cfg, mapper, 6, 32, 7, 43)
+    model.train()
+    pe = model.feature_extractor.patch_embed
+    x, y = orc.make_batch(44, 3, 6, 32, 7)
+    arrays, draws = {}, []
+    with torch.no_grad():
+        xs = pe.proj(x.unsqueeze(1))
+        xs = torch.nn.functional.normalize(rearrange(xs, "b d c h w -> b c (h w d)"), p=2, dim=-1)
+        cos = torch.einsum("b c d, b e d -> b c e", xs, xs).mean(dim=0)
+    arrays["cos"] = cos.numpy()
+    for k, (pyseed, tseed) in enumerate([(11, 21), (12, 22), (13, 23)]):
+        pe.counter.clear()
+        random.seed(pyseed)
+        torch.manual_seed(tseed)
+        model.zero_grad()
+        out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+        loss.backward()
+        # replay the documented draw order with the cosine row above
+        rng = random.Random(pyseed)
+        torch.manual_seed(tseed)
+        kk = rng.randint(1, 6)
+        anchor = rng.randint(0, 5)
+        prob = torch.softmax((1 - cos[anchor]) / 0.05, dim=-1)
+        ind = torch.multinomial(prob, kk, replacement=False).tolist()
+        if anchor not in ind:
+            ind[-1] = anchor
+        picked = [mapper["train"][i] for i in ind]
+        assert sorted(pe.counter.keys()) == sorted(picked), (dict(pe.counter), picked)
+        arrays[f"d{k}_picked"] = np.array(picked)
+        arrays[f"d{k}_logits"] = out.detach().numpy()
+        arrays[f"d{k}_loss"] = np.array(loss.item())
+        draws.append(dict(pyseed=pyseed, tseed=tseed, anchor=anchor, k=kk))
+        print(f"  hcs_proj draw {k}: picked={picked} loss={loss.item():.6f}")
+    save("hcs_proj", dict(cfg=cfg, mapper=mapper, n_channels=6, img=32, num_classes=7, B=3, seed=43, draws=draws), arrays)
+
+
+def case_init_stats(dichavit, loss_fn):
+    """Initialisation (dichavit.py:505-516, 60-65, 83-89, 803-805; utils.py:477-517): per-parameter moments and the first
+    values of the REAL reference's freshly constructed module under torch.manual_seed(s) on the CPU.  Data only."""
+    import contextlib, io
+    arrays, meta = {}, dict(torch_version=torch.__version__, variants=[])
+    for v, (kw, n_ch, img, K, seed) in enumerate([(dict(), 8, 224, 161, 1234),
+                                                  (dict(orthogonal_channel_emb_init=False, proxy_orthogonal_init=True, patch_size=8), 18, 32, 17, 77)]):
+        cfg = base_cfg(**kw)
+        full = Cfg(cfg, in_channel_names=[f"c{i}" for i in range(n_ch)], img_size=[img], num_classes=K)
+        torch.manual_seed(seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = dichavit(full, mapper={"train": list(range(n_ch))})
+        names = []
+        for name, p in m.named_parameters():
+            if name.startswith("adaptive_interface"):
+                continue
+            t = p.detach().double().flatten()
+            arrays[f"v{v}/{name}"] = np.array([t.numel(), t.mean().item(), t.std(unbiased=False).item() if t.numel() > 1 else 0.0,
+                                               t.min().item(), t.max().item(), t.sum().item(), (t * t).sum().item()] + t[:4].tolist()
+                                              + [0.0] * max(0, 4 - t.numel()))
+            names.append(name)
+        meta["variants"].append(dict(cfg=cfg, n_channels=n_ch, img=img, num_classes=K, seed=seed, names=names))
+    save("init_stats", meta, arrays)
+
+
 CASES = dict(tokendrop=case_tokendrop, resolution=case_resolution, schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
-             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, resume=case_resume)
+             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, resume=case_resume,
+             chammi_hcs=case_chammi_hcs, jumpcp_b16=case_jumpcp_b16, base64=case_base64, resolution_quirk=case_resolution_quirk,
+             hcs_proj=case_hcs_proj, init_stats=case_init_stats)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -14,6 +14,24 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _collect(procs, q, world, timeout=400):
+    """Results of all ranks; fails as soon as a rank dies instead of waiting for the queue to time out."""
+    import queue as _q
+    import time as _t
+    res, t0 = [], _t.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2))
+        except _q.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or _t.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail(f"a rank exited with {dead} (or timed out) before reporting")
+    return res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -33,6 +51,9 @@ class _Stub(torch.nn.Module):
         self._enc_params = [self.inside]
         self._arena = None
         self._dp = None
+
+    def _enc_param_list(self):
+        return [self.inside]
 
 
 def _worker(rank, world, port, q):
@@ -83,7 +104,7 @@ def test_dp_reducer_gloo_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = _collect(procs, q, world)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -94,6 +115,119 @@ def test_dp_reducer_gloo_world2():
         assert unused_none
         # 6 layers x 4 KB merged into >= 12 KB buckets + head + tail + 2 hooked params: fewer collectives than slices
         assert 4 <= nb <= 8, nb
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The REAL DiChaViT object (parameter arena, gradient arena, autograd node, _run_backward's data-parallel logic) under
+# DataParallel on two gloo ranks.  Only the two kernel-sequence methods are replaced by CPU stand-ins that produce
+# deterministic, rank- and pass-dependent "gradients" in the arena and report the layer slices exactly as the HIP
+# backward does (final norm, blocks last to first, tokeniser).  Follows INTEGRATION.md's call order (hooks BEFORE the
+# first forward), runs TWO backward passes per optimiser step (the CHAMMI step, trainer.py:846-935) and never calls
+# finalize() itself: whatever comes after loss.backward() must already see reduced gradients.
+def _real_model_worker(rank, world, port, q, grad_dtype, overlap):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import diverse_channel_vit_amd as dcv
+        from diverse_channel_vit_amd.dichavit import _EncoderFn
+
+        class Cfg(dict):
+            __getattr__ = dict.get
+
+        cfg = Cfg(name="dichavit", pretrained_model_name="tiny", patch_size=8, temperature=0.07, learnable_temp=False, enable_sample=False,
+                  use_channelvit_channels=True, orthogonal_channel_emb_init=True, dropout_tokens_hcs="none", freeze_channel_emb=False,
+                  block_type="block", hcs_sampling="none", hcs_sampling_temp=0.1, proxy_loss_lambda=0.001, ortho_loss_v1_lambda=0.001,
+                  drop_path_rate=0.0, gamma_s=1.0, gamma_d=4.0, reverse_pos_pairs=True, use_square=False,
+                  in_channel_names=["a", "b", "c"], img_size=[32], num_classes=5)
+        torch.manual_seed(7 + rank)  # different initial weights per rank: broadcast_parameters must equalise them
+        model = dcv.dichavit(cfg, mapper={"train": [0, 1, 2]})
+        dp = dcv.DataParallel(model, min_bucket_bytes=1 << 20, grad_dtype=grad_dtype, overlap=overlap)
+        dp.broadcast_parameters(0)
+        dp.hook_misc_params()  # BEFORE the arena exists (INTEGRATION.md order)
+        n_hooked = len(dp._hooks)
+        model._ensure_arena(torch.device("cpu"))
+        dp.broadcast_parameters(0)
+        fe = model.feature_extractor
+        D, B = model.dim, 2
+        state = {"pass": 0}
+
+        def fake_forward(x, ch_idx_dev, C, E, pos_tab, want_ortho, save, keep=None, st_scale=None, st_shift=None, tok=None):
+            return dict(feat=torch.ones(B, D), stats=torch.zeros(B, 2), C=C, n=16)
+
+        def fake_backward_body(st, dfeat, dstats, ga, g, dp_, nt_kw):
+            k = state["pass"]
+            state["pass"] += 1
+            base = torch.arange(ga.numel(), dtype=torch.float32) % 97
+            ga.copy_(base * (rank + 1) * 0.25 + (k + 1))  # exactly representable in bf16 too (small integers and quarters)
+            dp_.grad_ready(ga, *model._range_of([fe.norm.weight, fe.norm.bias]))
+            for li in range(len(fe.blocks) - 1, -1, -1):
+                blk = fe.blocks[li]
+                dp_.grad_ready(ga, *model._range_of([blk.norm1.weight, blk.mlp.fc2.bias]))
+            dp_.grad_ready(ga, *model._range_of([fe.cls_token, fe.patch_embed.proj.bias]))
+            dp_.flush()
+            grads = [model._gview(ga, p) for p in model._enc_params]
+            return torch.full((st["C"], D), float(rank + 1)), torch.full((st["n"] + 1, D), float(2 * rank + 1)), grads
+
+        model._run_forward = fake_forward
+        model._run_backward_body = fake_backward_body
+        x = torch.zeros(B, 3, 32, 32, requires_grad=False)
+        head = model.classifer_head
+        for k in range(2):  # two backward passes, gradients accumulate
+            E = fe.patch_embed.channel_embed(torch.tensor([0, 1, 2]))
+            pos_tab = model._pos_table(3, 16, 32, 32)
+            feat, stats = _EncoderFn.apply(model, None, 3, False, None, None, x, E, pos_tab, *model._enc_params)
+            loss = head(feat).sum() * (rank + 1) + stats.sum()
+            loss.backward()  # no finalize() here: the backward is self-synchronising
+        assert not dp._works and dp._pending is None and not dp._deferred
+        # expectation: sum over the two passes of the rank AVERAGE of each pass's arena
+        n = model._enc_size
+        base = (torch.arange(n, dtype=torch.float32) % 97)
+        avg_rank = sum(r + 1 for r in range(world)) / world
+        expect = base * avg_rank * 0.25 * 2 + (1 + 2)
+        got = torch.cat([p.grad.reshape(-1) for p in model._enc_params])
+        sizes = [p.numel() for p in model._enc_params]
+        want = torch.cat([expect[o:o + s_] for o, s_ in zip(model._enc_off, sizes)])
+        # bf16 exchange: the rank sum is rounded to 8 significant bits (twice: per pass)
+        ok_enc = torch.allclose(got, want, rtol=0 if grad_dtype == torch.float32 else 2.0 ** -7, atol=1e-5)
+        # channel_embed: rows get dE = rank+1 per pass -> average over ranks, times 2 passes (a parameter outside the arena node)
+        ce = fe.patch_embed.channel_embed.weight.grad
+        ok_misc = torch.allclose(ce, torch.full_like(ce, 2 * avg_rank), atol=1e-5 if grad_dtype == torch.float32 else 2e-2)
+        hw = head.weight.grad  # d/dW of sum(head(ones[B, D])) * (rank+1) = B * (rank+1) per entry per pass
+        ok_head = torch.allclose(hw, torch.full_like(hw, 2 * B * avg_rank), atol=1e-5 if grad_dtype == torch.float32 else 4e-2)
+        # all ranks identical afterwards
+        flat = torch.cat([got, ce.reshape(-1), hw.reshape(-1)])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        ok_same = all(torch.equal(gathered[0], t) for t in gathered)
+        q.put((rank, ok_enc, ok_misc, ok_head, ok_same, n_hooked, dp.buckets_launched, model.proxies.grad is None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("grad_dtype,overlap", [("float32", True), ("bfloat16", True), ("float32", False)])
+def test_real_model_two_backward_passes_gloo_world2(grad_dtype, overlap):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_real_model_worker, args=(r, world, port, q, getattr(torch, grad_dtype), overlap)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, world)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok_enc, ok_misc, ok_head, ok_same, n_hooked, nb, proxies_none in res:
+        assert ok_enc, f"rank {rank}: encoder gradients are not the sum over passes of the rank averages"
+        assert ok_misc and ok_head, f"rank {rank}: parameters outside the arena wrong"
+        assert ok_same, f"rank {rank}: ranks diverged"
+        assert proxies_none
+        # only the handful of parameters outside the encoder arena carry hooks (pos_embed, channel_embed, channel_emb_proxies,
+        # classifer_head.{weight,bias}, proxies) — not the ~150 encoder parameters
+        assert n_hooked <= 8, n_hooked
+        assert nb >= 2
 
 
 class _Fixed(torch.nn.Module):
@@ -131,7 +265,7 @@ def test_evaluate_sums_counts_over_ranks_gloo_world2():
     procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(world)]
+    res = _collect(procs, q, world)
     for p in procs:
         p.join(60)
     for rank, acc in res:

@@ -38,47 +38,88 @@ def _close(a, b, rtol, atol, what=""):
 GEMM_SHAPES = [(300, 384, 384), (128, 128, 64), (777, 1152, 384), (1000, 384, 1536), (257, 192, 192), (130, 576, 192)]
 
 
-@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_nt_epilogues(hip, M, N, K):
+def _check_gemm_nt(hip, M, N, K, **kw):
+    """All five Linear epilogues of dcv_gemm_nt_ex against fp32 torch.matmul on the same bf16 operands."""
     A, W = _bf(M, K, seed=1), _bf(N, K, scale=0.05, seed=2)
     bias = _f(N, scale=0.1, seed=3)
     ref = A.float() @ W.float().t()
     # bias -> bf16
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    hip.gemm_nt(A, W, hip.EPI_BIAS_BF16, out, bias=bias)
+    hip.gemm_nt(A, W, hip.EPI_BIAS_BF16, out, bias=bias, **kw)
     _close(out, ref + bias, 1e-2, 2e-2, "bias_bf16")
     # plain
-    hip.gemm_nt(A, W, hip.EPI_PLAIN_BF16, out)
+    hip.gemm_nt(A, W, hip.EPI_PLAIN_BF16, out, **kw)
     _close(out, ref, 1e-2, 2e-2, "plain_bf16")
     # bias + gelu: out = GELU'(z), out2 = GELU(z), z = acc + bias
     h = torch.empty_like(out)
-    hip.gemm_nt(A, W, hip.EPI_BIAS_GELU_BF16, out, bias=bias, out2=h)
+    hip.gemm_nt(A, W, hip.EPI_BIAS_GELU_BF16, out, bias=bias, out2=h, **kw)
     zr = (ref + bias).requires_grad_(True)
     hr = torch.nn.functional.gelu(zr)
     hr.sum().backward()
     _close(h, hr.detach(), 1e-2, 2e-2, "gelu h")
     _close(out, zr.grad, 1e-2, 2e-2, "gelu'")
+    del hr, zr
     # residual f32 in place
     x = _f(M, N, seed=4)
     x0 = x.clone()
-    hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, x, bias=bias)
+    hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, x, bias=bias, **kw)
     _close(x, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32")
     y = torch.empty_like(x)
-    hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, y, bias=bias, aux=x0)  # out-of-place residual
+    hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, y, bias=bias, aux=x0, **kw)  # out-of-place residual
     _close(y, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32 out-of-place")
     assert torch.equal(y, x)
+    del x, y, x0
     # gelu backward epilogue: acc * saved GELU'
     gp = _bf(M, N, seed=5)
-    hip.gemm_nt(A, W, hip.EPI_GELU_BWD_BF16, out, aux=gp)
+    hip.gemm_nt(A, W, hip.EPI_GELU_BWD_BF16, out, aux=gp, **kw)
     _close(out, ref * gp.float(), 1e-2, 2e-2, "gelu_bwd")
 
 
-@pytest.mark.parametrize("M,N,K", [(4100, 1152, 384), (4352, 384, 1536), (4608, 1536, 384), (5000, 384, 64)])
-def test_gemm_nt_384_wide_tiles(hip, M, N, K, monkeypatch):
-    """The 256 x 384 tile kernel (gemm_nt384, used for N % 384 == 0 where it pays) on every epilogue it carries, forced on
-    with DCV_NT384=1: full tiles, a partial last M tile, one and several k-stages, 1 / 3 / 4 column tiles."""
-    monkeypatch.setenv("DCV_NT384", "1")
-    test_gemm_nt_epilogues(hip, M, N, K)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_epilogues(hip, M, N, K):
+    _check_gemm_nt(hip, M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K", [(4100, 1152, 384), (4352, 384, 1536), (4608, 1536, 384), (5000, 384, 64), (300, 384, 128)])
+def test_gemm_nt_384_wide_tiles(hip, M, N, K):
+    """The 256 x 384 tile kernel (gemm_nt384, used for N % 384 == 0 where it pays) on every epilogue it carries, forced with
+    tile=TILE_WIDE: full tiles, a partial last M tile, one and several k-stages, 1 / 3 / 4 column tiles."""
+    _check_gemm_nt(hip, M, N, K, tile=hip.TILE_WIDE)
+
+
+# The headline step's GEMMs: M = 64 x 1569 = 100 416 token rows.  Both NT kernels are PERSISTENT: one workgroup per CU walks
+# 1 179 - 4 716 output tiles in several rounds, prefetching the next tile's first stages under the current tile's epilogue
+# (hand-counted vmcnt waits: csrc/gemm.hip `stores_behind`).  None of that runs when a launch has fewer tiles than CUs.
+HEADLINE_M = 64 * 1569
+HEADLINE_NK = [(1152, 384), (384, 384), (1536, 384), (384, 1536)]
+
+
+@pytest.mark.parametrize("tile", ["narrow", "wide"])
+@pytest.mark.parametrize("N,K", HEADLINE_NK)
+def test_gemm_nt_headline_shapes_multi_round(hip, N, K, tile):
+    """(i) of the persistence coverage: the exact shapes of bench.py's step, every epilogue, both tile shapes, many rounds
+    per workgroup, a partial last M tile (100 416 = 392 x 256 + 64)."""
+    _check_gemm_nt(hip, HEADLINE_M, N, K, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE)
+
+
+@pytest.mark.parametrize("grid_cap", [4, 8, 248])
+@pytest.mark.parametrize("M,N,K,tile", [(5000, 384, 384, "narrow"), (5000, 1152, 384, "wide"), (5100, 384, 1536, "wide"),
+                                        (5100, 1536, 384, "narrow"), (66000, 384, 384, "wide"), (33000, 1152, 384, "narrow")])
+def test_gemm_nt_forced_small_grids(hip, M, N, K, tile, grid_cap):
+    """(ii): few workgroups on a small problem, so that total tiles > grid: long tile walks (up to 60 rounds at 4 workgroups),
+    a partial last round, the `stores_behind` waits and the epilogue-overlapped prefetch all execute.  248 = the
+    data-parallel backward's grid (CUs minus the ones left to RCCL); the last two shapes have more tiles than that."""
+    _check_gemm_nt(hip, M, N, K, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE, grid_cap=grid_cap)
+
+
+def test_gemm_nt_auto_tile_rules(hip):
+    """AUTO picks the kernel by shape; an illegal forced variant is refused, not silently replaced."""
+    A, W = _bf(512, 384, seed=1), _bf(200, 384, seed=2)
+    out = torch.empty(512, 200, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        hip.gemm_nt(A, W, hip.EPI_PLAIN_BF16, out, tile=hip.TILE_WIDE)  # N % 384 != 0
+    hip.gemm_nt(A, W, hip.EPI_PLAIN_BF16, out, tile=hip.TILE_NARROW)
+    _close(out, A.float() @ W.float().t(), 1e-2, 2e-2, "narrow")
 
 
 def test_gemm_nt_patch_epilogue(hip):
@@ -96,19 +137,37 @@ def test_gemm_nt_patch_epilogue(hip):
     assert (x[:, 0] == 7.0).all()
 
 
-@pytest.mark.parametrize("M,P,Q", [(1000, 384, 384), (4100, 1152, 384), (333, 384, 1536), (64, 128, 128), (5000, 192, 64), (700, 384, 256)])
-def test_gemm_tn(hip, M, P, Q):
+def _check_gemm_tn(hip, M, P, Q, **kw):
     Y, X = _bf(M, P, seed=1), _bf(M, Q, seed=2)
     dW = _f(P, Q, seed=3)
     db = _f(P, seed=4)
     dW0, db0 = dW.clone(), db.clone()
-    hip.gemm_tn_acc(Y, X, dW, db)
+    hip.gemm_tn_acc(Y, X, dW, db, **kw)
     ref = Y.float().t() @ X.float()
     _close(dW, dW0 + ref, 1e-4, 3e-4 * math.sqrt(M), "dW")
     _close(db, db0 + Y.float().sum(0), 1e-4, 1e-4 * math.sqrt(M), "dbias")
     dW2 = torch.zeros(P, Q, device="cuda")
-    hip.gemm_tn_acc(Y, X, dW2, None)
+    hip.gemm_tn_acc(Y, X, dW2, None, **kw)
     _close(dW2, ref, 1e-4, 3e-4 * math.sqrt(M), "dW no bias")
+
+
+@pytest.mark.parametrize("M,P,Q", [(1000, 384, 384), (4100, 1152, 384), (333, 384, 1536), (64, 128, 128), (5000, 192, 64), (700, 384, 256)])
+def test_gemm_tn(hip, M, P, Q):
+    _check_gemm_tn(hip, M, P, Q)
+
+
+@pytest.mark.parametrize("tile", ["narrow", "wide"])
+@pytest.mark.parametrize("P,Q", [(1152, 384), (384, 384), (1536, 384), (384, 1536), (384, 256)])
+def test_gemm_tn_headline_rows(hip, P, Q, tile):
+    """The weight-gradient products of the headline step (reduction over 100 416 token rows split over one resident round of
+    workgroups, fp32 atomics), both tile shapes; the last shape is the tokeniser's (P^2 = 256 inputs)."""
+    _check_gemm_tn(hip, HEADLINE_M, P, Q, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE)
+
+
+@pytest.mark.parametrize("M", [31, 32, 33, 1000, 4099])
+def test_gemm_tn_wide_ragged_reduction(hip, M):
+    """384 x 128 kernel with reduction lengths around its 32-row stage (ragged last stage, fewer stages than the ring is deep)."""
+    _check_gemm_tn(hip, M, 384, 128, tile=hip.TILE_WIDE)
 
 
 @pytest.mark.parametrize("M,D", [(1000, 384), (37, 192), (513, 768)])

@@ -221,3 +221,76 @@ def test_token_drop_goldens():
         assert abs(loss.item() - float(a[f"d{k}_loss"])) < 5e-6
         g = sd["feature_extractor.pos_embed"].grad.numpy()
         assert np.abs(g - a[f"d{k}_gpos"]).max() < 2e-4 * np.abs(a[f"d{k}_gpos"]).max()
+
+
+def test_chammi_hcs_goldens():
+    """BASELINE config 3 as specified: CHAMMI chunks WITH enable_sample=True — HCS on the non-identity mapper (global ids vs
+    positions), two rounds, gradients accumulating over a round's chunks."""
+    meta, a = load_golden("chammi_hcs")
+    cfg = dict(meta["cfg"])
+    k = 0
+    for rnd in range(2):
+        sd = _state(meta)
+        for d in meta["draws"][3 * rnd:3 * rnd + 3]:
+            ch = meta["mapper"][d["chunk"]]
+            rng = random.Random(d["pyseed"])
+            torch.manual_seed(d["tseed"])
+            rows = sd["feature_extractor.patch_embed.channel_embed.weight"].detach().float()[ch]
+            picked, idx = orc.hcs_sample(rows, ch, d["mode"], d["temp"], rng)
+            assert picked == a[f"d{k}_picked"].tolist()
+            assert idx == [ch.index(c) for c in picked] and (d["chunk"] == "Allen" or picked != idx)  # ids != positions off Allen
+            x, y = orc.make_batch(d["batch_seed"], 2, len(ch), meta["img"], meta["num_classes"], dtype=torch.float64)
+            loss, main, extra, feat = orc.chammi_loss(sd, x, y, cfg, picked, idx)
+            loss.backward()
+            assert np.abs(feat.detach().numpy() - a[f"d{k}_feat"]).max() < 2e-5
+            assert abs(extra.item() - float(a[f"d{k}_extra"])) < 2e-6
+            assert abs(loss.item() - float(a[f"d{k}_loss"])) < 1e-5
+            k += 1
+        _check_grads(sd, {kk[len(f"r{rnd}/"):]: v for kk, v in a.items() if kk.startswith(f"r{rnd}/")})
+
+
+def test_resolution_quirk_golden():
+    """interpolate_pos_encoding's early-out with several channels (4 ch x 4 patches = the model's 16 grid positions): the raw
+    table is added token by token across the channels."""
+    meta, a = load_golden("resolution_quirk")
+    sd = _state(meta)
+    x, y = orc.make_batch(196, 2, 4, meta["img_in"], 6, dtype=torch.float64)
+    loss, main, extra, logits = orc.train_loss(sd, x, y, meta["cfg"], [0, 1, 2, 3], [0, 1, 2, 3])
+    loss.backward()
+    assert np.abs(logits.detach().numpy() - a["logits"]).max() < 2e-5
+    assert abs(loss.item() - float(a["loss"])) < 5e-6
+    for key, name in (("gpos", "feature_extractor.pos_embed"), ("gchan", "feature_extractor.patch_embed.channel_embed.weight"),
+                      ("gcls", "feature_extractor.cls_token")):
+        g = sd[name].grad.numpy()
+        assert np.abs(g - a[key]).max() < 2e-4 * np.abs(a[key]).max(), key
+
+
+def test_hcs_proj_golden():
+    """hcs_sampling=lowest_cosine_prob_proj: the projected-input cosine matrix and the subsets the reference drew from it."""
+    meta, a = load_golden("hcs_proj")
+    sd = _state(meta, dtype=torch.float32)
+    x, y = orc.make_batch(44, 3, 6, 32, 7)
+    with torch.no_grad():
+        cos = orc.proj_cosine(sd, x, meta["cfg"]["patch_size"])
+    assert np.abs(cos.numpy() - a["cos"]).max() < 2e-6
+    for k, d in enumerate(meta["draws"]):
+        sd64 = _state(meta)
+        rng = random.Random(d["pyseed"])
+        torch.manual_seed(d["tseed"])
+        picked, idx = orc.hcs_sample(None, meta["mapper"]["train"], "lowest_cosine_prob_proj", meta["cfg"]["hcs_sampling_temp"], rng,
+                                     proj_cos=torch.from_numpy(a["cos"]))
+        assert picked == a[f"d{k}_picked"].tolist()
+        loss, main, extra, logits = orc.train_loss(sd64, x.double(), y, meta["cfg"], picked, idx)
+        assert np.abs(logits.detach().numpy() - a[f"d{k}_logits"]).max() < 2e-5
+        assert abs(loss.item() - float(a[f"d{k}_loss"])) < 5e-6
+
+
+def test_headline_b16_golden_forward():
+    """jumpcp_s_b16 (the headline architecture at batch 16, the fixture behind the model-level multi-round GEMM test):
+    oracle forward on the first 2 images of the batch against the reference's logits (per-image independence)."""
+    meta, a = load_golden("jumpcp_s_b16")
+    sd = _state(meta, dtype=torch.float32)
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], 8, 224, 161)
+    with torch.no_grad():
+        logits, extra = orc.forward(sd, x[:2], meta["cfg"], list(range(8)), list(range(8)))
+    assert np.abs(logits.numpy() - a["logits"][:2]).max() < 5e-5
