@@ -23,6 +23,9 @@ namespace {
 // Two earlier forms measured slower at the headline shape (tools/ab_bench.py): register-staged K/V with per-use address
 // arithmetic 436-448 us; a 4-stage ring with the NEXT tile's score MFMAs issued ahead of the softmax (register ping-pong,
 // 228 VGPRs, 2 waves per SIMD) 418-430 us; this one 397-405 us.  Occupancy beat intra-wave overlap.
+#if DCV_WPE_FWD
+DCV_WAVES_PER_SIMD(DCV_WPE_FWD)
+#endif
 __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
     constexpr int ST = 3;
     __shared__ __attribute__((aligned(16))) char sKV[ST * KV_STAGE_BYTES];
@@ -83,12 +86,14 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
     float m = -INFINITY, l = 0.f;
     const float c = a.scale * LOG2E;
 
-    auto tile = [&](auto MASKED, int t, int slot) {
+    // COMPUTE = false: a wave without a valid query row only keeps the ring going; separate loops, not a branch in the loop
+    // (attn_bwd.hip: the branch made the accumulators loop-carried phis resolved with register copies)
+    auto tile = [&](auto MASKED, auto COMPUTE, int t, int slot) {
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (t + 2 < nt) kv_issue(t + 2, slot == 0 ? 2 : slot - 1);
-        if (!active) return;
+        if constexpr (!decltype(COMPUTE)::value) return;
         const int so = slot * KV_STAGE_BYTES;
         int ro[4], co[2][2];
 #pragma unroll
@@ -153,11 +158,19 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
     using Yes = std::integral_constant<bool, true>;
     const int nfull = a.N / 64;
     int slot = 0;
-    for (int t = 0; t < nfull; ++t) {
-        tile(No{}, t, slot);
-        slot = (slot == ST - 1) ? 0 : slot + 1;
+    if (active) {
+        for (int t = 0; t < nfull; ++t) {
+            tile(No{}, Yes{}, t, slot);
+            slot = (slot == ST - 1) ? 0 : slot + 1;
+        }
+        if (nfull < nt) tile(Yes{}, Yes{}, nfull, slot);
+    } else {
+        for (int t = 0; t < nfull; ++t) {
+            tile(No{}, No{}, t, slot);
+            slot = (slot == ST - 1) ? 0 : slot + 1;
+        }
+        if (nfull < nt) tile(Yes{}, No{}, nfull, slot);
     }
-    if (nfull < nt) tile(Yes{}, nfull, slot);
 
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;

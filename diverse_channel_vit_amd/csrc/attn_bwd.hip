@@ -38,6 +38,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 // once plus an immediate, and only the partial last tile carries the masking code: 100 vector instructions per tile,
 // 129 VGPRs (3 waves per SIMD), 551 -> 437 us at the headline shape.
 constexpr int DQ_STAGES = 3;
+#if DCV_WPE_DQ
+DCV_WAVES_PER_SIMD(DCV_WPE_DQ)
+#endif
 __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char sKV[DQ_STAGES * KV_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
@@ -129,12 +132,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     zero_acc(dq[0]);
     zero_acc(dq[1]);
 
-    auto tile = [&](auto MASKED, int t, int slot) {
+    // COMPUTE = false: a wave without a single valid query row only keeps the ring going (same DMA and barrier count).  The
+    // two cases are separate LOOPS (below), not a branch inside one loop: with the branch inside, the accumulators became
+    // loop-carried phis that hipcc resolved with a full register copy per tile (16 v_mov_b64) and twice the registers.
+    auto tile = [&](auto MASKED, auto COMPUTE, int t, int slot) {
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");  // younger: stage t+1
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
         if (t + 2 < nt) kv_issue(t + 2, slot == 0 ? 2 : slot - 1);  // (t + 2) % 3
-        if (!active) return;
+        if constexpr (!decltype(COMPUTE)::value) return;
         const int so = slot * KV_STAGE_BYTES;
         int ro[4], co[2][2];
 #pragma unroll
@@ -176,11 +182,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     using Yes = std::integral_constant<bool, true>;
     const int nfull = a.N / 64;
     int slot = 0;
-    for (int t = 0; t < nfull; ++t) {
-        tile(No{}, t, slot);
-        slot = (slot == DQ_STAGES - 1) ? 0 : slot + 1;
+    if (active) {
+        for (int t = 0; t < nfull; ++t) {
+            tile(No{}, Yes{}, t, slot);
+            slot = (slot == DQ_STAGES - 1) ? 0 : slot + 1;
+        }
+        if (nfull < nt) tile(Yes{}, Yes{}, nfull, slot);
+    } else {
+        for (int t = 0; t < nfull; ++t) {
+            tile(No{}, No{}, t, slot);
+            slot = (slot == DQ_STAGES - 1) ? 0 : slot + 1;
+        }
+        if (nfull < nt) tile(Yes{}, No{}, nfull, slot);
     }
-    if (nfull < nt) tile(Yes{}, nfull, slot);
 
     if (q >= a.Nq && q < a.N) {  // rows of this tile beyond the processed ones: dQ = 0
         bf16_t* dst = a.dqkv + ((size_t)b * a.N + q) * rs + hh * 64;
@@ -207,6 +221,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
 // the file is compiled with -fno-slp-vectorize: hipcc's SLP packing of the softmax-gradient arithmetic cost 48 v_mov per tile.)
 constexpr int DKV_STAGES = 4, DKV_STAGE_BYTES = 16384 + 1024;  // Q tile | dO tile | lse[64] | delta[64] | 512 B scratch
 constexpr int DKV_DMA_PER_WAVE = 5;
+#if DCV_WPE_DKDV
+DCV_WAVES_PER_SIMD(DCV_WPE_DKDV)
+#endif
 __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char sQO[DKV_STAGES * DKV_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
@@ -283,14 +300,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     zero_acc(dv[0]);
     zero_acc(dv[1]);
 
-    auto tile = [&](auto MASKED, int t, int slot) {
+    auto tile = [&](auto MASKED, auto COMPUTE, int t, int slot) {  // COMPUTE: see attn_bwd_dq2_kernel
         const int rem = nt - 1 - t;  // younger stages in flight: min(rem, 2)
         if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DKV_DMA_PER_WAVE) : "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DKV_DMA_PER_WAVE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
         if (t + 3 < nt) issue(t + 3, (slot + 3) & 3);
-        if (!active) return;
+        if constexpr (!decltype(COMPUTE)::value) return;
         const int so = slot * DKV_STAGE_BYTES;
         int ro[4], co[2][2];
 #pragma unroll
@@ -347,8 +364,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     using No = std::integral_constant<bool, false>;
     using Yes = std::integral_constant<bool, true>;
     const int nfull = a.Nq / 64;
-    for (int t = 0; t < nfull; ++t) tile(No{}, t, t & 3);
-    if (nfull < nt) tile(Yes{}, nfull, nfull & 3);
+    if (active) {
+        for (int t = 0; t < nfull; ++t) tile(No{}, Yes{}, t, t & 3);
+        if (nfull < nt) tile(Yes{}, Yes{}, nfull, nfull & 3);
+    } else {
+        for (int t = 0; t < nfull; ++t) tile(No{}, No{}, t, t & 3);
+        if (nfull < nt) tile(Yes{}, No{}, nfull, nfull & 3);
+    }
 
     if (key < a.N) {
         bf16_t* dkp = a.dqkv + ((size_t)b * a.N + key) * rs + D + hh * 64;

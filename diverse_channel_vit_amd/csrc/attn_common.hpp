@@ -8,6 +8,20 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// amdgpu_waves_per_eu(n, n) tells hipcc how many waves per SIMD the kernel is launched for, i.e. how many VGPRs it MAY use
+// (512 / n).  Without it the scheduler aims at a lower register count than the occupancy needs and issues every LDS fragment
+// read just before the MFMA that consumes it (ds_read; s_waitcnt lgkmcnt(0); v_mfma — the full LDS latency exposed per MFMA).
+#define DCV_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#ifndef DCV_WPE_FWD
+#define DCV_WPE_FWD 3
+#endif
+#ifndef DCV_WPE_DQ
+#define DCV_WPE_DQ 3
+#endif
+#ifndef DCV_WPE_DKDV
+#define DCV_WPE_DKDV 2
+#endif
+
 struct AttnArgs {
     const bf16_t* qkv;  // [B,N,3,H,64]
     bf16_t* o;          // [B,N,H*64]           (fwd out / bwd in)

@@ -229,7 +229,7 @@ def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None):
     with _timer(lambda: ("attn_bwd_dq2_kernel", f"B{B} N{N} H{H} Nq{nq}", 1 * prod, 3 * prod, 2.0 * B * (N * 3 * D_ + nq * 3 * D_))):  # also writes the row statistics
         rc = lib.dcv_attn_bwd_dq_rows(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dq")
-    with _timer(lambda: ("attn_bwd_dkdv2_kernel", f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 2 * D_ + N * 2 * D_))):
+    with _timer(lambda: ("attn_bwd_dkdv2_kernel", f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 1 * D_ + N * 2 * D_))):
         rc = lib.dcv_attn_bwd_dkdv_rows(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dkdv")
 
