@@ -191,6 +191,9 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
 #ifndef DCV_TABL
 #define DCV_TABL 0  // gemm_tn timing-only ablations: 1 = no atomic epilogue, 2 = no MFMA / transposed reads
 #endif
+#ifndef DCV_STAMP
+#define DCV_STAMP 0
+#endif
 #ifndef DCV_GABL
 #define DCV_GABL 0  // timing-only ablations: 1 = no epilogue, 2 = no MFMA/LDS reads, 3 = no operand DMA
 #endif
@@ -288,6 +291,9 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(bz[e]));
     }
 
+#if DCV_STAMP
+    unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = clock64();
+#endif
     for (;;) {
         f32x16 acc[2][2];
 #pragma unroll
@@ -333,6 +339,10 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
 #endif
         }
         __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: its buffer (g-1)%3 now holds the slabs
+#if DCV_STAMP
+        const unsigned long long st_t1 = clock64();
+        st_loop += st_t1 - st_t0;
+#endif
 
         // ---- epilogue of `cur`, overlapped with the first two stages of the next tile ----
         const int Ln = Lnext;
@@ -381,6 +391,11 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
             }
         }
 #endif
+#if DCV_STAMP
+        st_t0 = clock64();
+        st_epi += st_t0 - st_t1;
+        ++st_n;
+#endif
         if (!has_next) break;
         if constexpr (HAS_BIAS) {
 #pragma unroll
@@ -390,6 +405,12 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         cur = nxt;
         L = Ln;
     }
+#if DCV_STAMP
+    if (tid == 0 && a.aux2 && EPI != DCV_EPI_PATCH) {
+        unsigned long long* sp = (unsigned long long*)a.aux2 + 4 * blockIdx.x;
+        sp[0] = st_loop; sp[1] = st_epi; sp[2] = st_n; sp[3] = clock64();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -471,6 +492,9 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     issue(m0, n0, 0, smem_base);
     bool stores_behind = false;
 
+#if DCV_STAMP  // diagnostic build only (tools/gemm_stamp.py): per-workgroup cycles in the k-loop vs the epilogue, written through aux2
+    unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = clock64();
+#endif
     for (;;) {
         f32x16 acc[2][6];
 #pragma unroll
@@ -503,6 +527,10 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             }
         }
         __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: buffer (g-1)&1 now holds the slabs
+#if DCV_STAMP
+        const unsigned long long st_t1 = clock64();
+        st_loop += st_t1 - st_t0;
+#endif
 
         // ---- epilogue, overlapped with the first stage of the next tile (into the other buffer) ----
         const int Ln = Lnext;
@@ -543,12 +571,23 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
                 }
             }
         }
+#if DCV_STAMP
+        st_t0 = clock64();
+        st_epi += st_t0 - st_t1;
+        ++st_n;
+#endif
         if (!has_next) break;
         stores_behind = full;
         m0 = m0n;
         n0 = n0n;
         L = Ln;
     }
+#if DCV_STAMP
+    if (tid == 0 && a.aux2) {
+        unsigned long long* sp = (unsigned long long*)a.aux2 + 4 * blockIdx.x;
+        sp[0] = st_loop; sp[1] = st_epi; sp[2] = st_n; sp[3] = clock64();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -167,9 +167,9 @@ def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T
     lib = load()
 
     def describe():
-        wide = lib.dcv_gemm_nt_pick(M, N, K, epilogue, tile) == TILE_WIDE
+        kind = "gemm_nt384" if lib.dcv_gemm_nt_pick(M, N, K, epilogue, tile) == TILE_WIDE else "gemm_nt"
         nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (_EPI_OUT_BYTES[epilogue] + _EPI_AUX_BYTES[epilogue])
-        return f"gemm_nt{'384' if wide else ''}_kernel<{epilogue}>", f"M{M} N{N} K{K}", 2.0 * M * N * K, None, nbytes
+        return f"{kind}_kernel<{epilogue}>", f"M{M} N{N} K{K}", 2.0 * M * N * K, None, nbytes
 
     with _timer(describe):
         rc = lib.dcv_gemm_nt_ex(_p(A), K, _p(W), K, M, N, K, epilogue, _p(bias), _p(out), ldo, _p(out2), ldo2, _p(aux), ldaux,

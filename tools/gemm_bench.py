@@ -1,0 +1,35 @@
+"""Times dcv_gemm_nt_ex at the headline step's shapes for every legal tile variant, interleaved in one process.
+python tools/gemm_bench.py   ->  median / min microseconds per (product, epilogue, variant)."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diverse_channel_vit_amd import hip
+hip.load()
+M, D = 64 * 1569, 384
+bf = torch.bfloat16
+torch.manual_seed(0)
+A = torch.randn(M, D, device="cuda").to(bf); A3 = torch.randn(M, 3 * D, device="cuda").to(bf); A4 = torch.randn(M, 4 * D, device="cuda").to(bf)
+cases = [("qkv        N1152 K384  bias", A, 3 * D, hip.EPI_BIAS_BF16), ("fc1        N1536 K384  bias+gelu", A, 4 * D, hip.EPI_BIAS_GELU_BF16),
+         ("gelu-bwd   N1536 K384", A, 4 * D, hip.EPI_GELU_BWD_BF16), ("dgrad fc1T N384  K1536 plain", A4, D, hip.EPI_PLAIN_BF16),
+         ("dgrad qkvT N384  K1152 plain", A3, D, hip.EPI_PLAIN_BF16), ("dgrad proj N384  K384  plain", A, D, hip.EPI_PLAIN_BF16)]
+names = {hip.TILE_NARROW: "narrow", hip.TILE_WIDE: "wide"}
+rounds = int(os.environ.get("GB_ROUNDS", 12))
+for name, a, N, epi in cases:
+    K = a.shape[1]
+    W = (torch.randn(N, K, device="cuda") * 0.05).to(bf)
+    bias = torch.zeros(N, device="cuda")
+    out = torch.empty(M, N, dtype=bf, device="cuda")
+    out2 = torch.empty(M, N, dtype=bf, device="cuda") if epi == hip.EPI_BIAS_GELU_BF16 else None
+    aux = torch.randn(M, N, device="cuda").to(bf) if epi == hip.EPI_GELU_BWD_BF16 else None
+    res = {t: [] for t in names}
+    for rnd in range(rounds):
+        for t in names:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                hip.gemm_nt(a, W, epi, out, bias=bias, out2=out2, aux=aux, tile=t)
+            e.record(); torch.cuda.synchronize()
+            if rnd >= 2:
+                res[t].append(s.elapsed_time(e) * 1e3 / 3)
+    print(f"{name:34s} " + "  ".join(f"{names[t]} {np.median(v):7.1f} (min {min(v):7.1f})" for t, v in res.items()), flush=True)
