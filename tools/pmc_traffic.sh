@@ -2,20 +2,20 @@
 # round-end evidence: (1) default bench line, (2) rocprofv3 --kernel-trace --stats of a short eager bench, (3) separate --pmc
 # passes for HBM traffic (FETCH_SIZE, WRITE_SIZE).  Small summaries under gpurun_out/v5/ (raw traces are deleted on the box).
 set -e
-ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/v5; mkdir -p $OUT
+ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/${1:-r02_v1}; mkdir -p $OUT
 cd $ROOT && timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err && tail -1 $OUT/bench.json | cut -c1-200
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/v5stats -o s -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > $OUT/stats.log 2>&1 && echo stats done
-find /tmp/v5stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dcvstats -o s -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > $OUT/stats.log 2>&1 && echo stats done
+find /tmp/dcvstats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/v5pmc_$c -o p -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/pmc_$c.log 2>&1 && echo "$c done"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/dcvpmc_$c -o p -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/pmc_$c.log 2>&1 && echo "$c done"
 done
-python3 - <<'PY'
+DCV_OUT=${1:-r02_v1} python3 - <<'PY'
 import csv, glob, json, collections, re, os
-out = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/v5/pmc_traffic.json"
+out = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/" + os.environ.get("DCV_OUT", "r02_v1") + "/pmc_traffic.json"
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob(f"/tmp/v5pmc_{c}/**/*counter_collection.csv", recursive=True):
+    for f in glob.glob(f"/tmp/dcvpmc_{c}/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != c:
                 continue
