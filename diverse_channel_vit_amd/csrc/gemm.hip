@@ -747,7 +747,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 // X columns 0-127), each 256-byte row swizzled per 64-byte segment (segment ^= row & 3) so that ds_read_b64_tr_b16 is
 // conflict-free; every DMA instruction moves 4 rows x 256 contiguous bytes.  Used when P % 384 == 0 and Q % 128 == 0
 // (all DiChaViT-S/B shapes); otherwise gemm_tn_kernel.
-constexpr int T3_BK = 32, T3_STAGES = 4, T3_IMG = T3_BK * 256, T3_STAGE_BYTES = 4 * T3_IMG;  // 8 KB images, 32 KB stages
+#ifndef DCV_T3_STAGES
+#define DCV_T3_STAGES 4
+#endif
+constexpr int T3_BK = 32, T3_STAGES = DCV_T3_STAGES, T3_IMG = T3_BK * 256, T3_STAGE_BYTES = 4 * T3_IMG;  // 8 KB images, 32 KB stages
 
 __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[T3_STAGES * T3_STAGE_BYTES];  // 128 KB: one workgroup per CU
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
 
 #define T3_ISSUE(kt_)                                                                                     \
     {                                                                                                     \
-        const unsigned sb_ = smem_base + ((kt_) & (T3_STAGES - 1)) * T3_STAGE_BYTES + dma_off;            \
+        const unsigned sb_ = smem_base + ((kt_) % T3_STAGES) * T3_STAGE_BYTES + dma_off;                  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
             const int m_ = min(m_begin + (kt_) * T3_BK + prow0 + 4 * j, m_end - 1); /* tail rows: zeroed in LDS below */ \
             glds16(gsrc + (size_t)m_ * ld + lc8[j], sb_ + j * 1024);                                      \
@@ -824,13 +827,14 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
     for (int e = 0; e < 8; ++e) bs[e] = 0.f;
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int rem = nk - 1 - kt;
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const int rem = nk - 1 - kt;  // younger stages in flight: min(rem, T3_STAGES - 2), 4 DMA pieces per wave each
+        if (T3_STAGES >= 5 && rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + T3_STAGES - 1 < nk) T3_ISSUE(kt + T3_STAGES - 1)
-        char* st = smem + (kt & (T3_STAGES - 1)) * T3_STAGE_BYTES;
+        char* st = smem + (kt % T3_STAGES) * T3_STAGE_BYTES;
         if (kt == nk - 1 && last_valid < T3_BK) {  // ragged end of the reduction: rows that do not exist must contribute 0
             const int nbad = T3_BK - last_valid;
             for (int idx = tid; idx < nbad * 64; idx += 512) {
