@@ -37,7 +37,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 // through a 3-stage LDS-DMA ring with scalar tile bases (as in the forward), every LDS address is a per-lane offset computed
 // once plus an immediate, and only the partial last tile carries the masking code: 100 vector instructions per tile,
 // 129 VGPRs (3 waves per SIMD), 551 -> 437 us at the headline shape.
-constexpr int DQ_STAGES = 3;
+#ifndef DCV_DQ_STAGES
+#define DCV_DQ_STAGES 3
+#endif
+constexpr int DQ_STAGES = DCV_DQ_STAGES;
 #if DCV_WPE_DQ
 DCV_WAVES_PER_SIMD(DCV_WPE_DQ)
 #endif
@@ -136,10 +139,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     // two cases are separate LOOPS (below), not a branch inside one loop: with the branch inside, the accumulators became
     // loop-carried phis that hipcc resolved with a full register copy per tile (16 v_mov_b64) and twice the registers.
     auto tile = [&](auto MASKED, auto COMPUTE, int t, int slot) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");  // younger: stage t+1
+        if (DQ_STAGES >= 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");  // younger: stage t+1
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
-        if (t + 2 < nt) kv_issue(t + 2, slot == 0 ? 2 : slot - 1);  // (t + 2) % 3
+        if (t + DQ_STAGES - 1 < nt) kv_issue(t + DQ_STAGES - 1, slot == 0 ? DQ_STAGES - 1 : slot - 1);  // (t + STAGES - 1) % STAGES
         if constexpr (!decltype(COMPUTE)::value) return;
         const int so = slot * KV_STAGE_BYTES;
         int ro[4], co[2][2];

@@ -17,6 +17,8 @@ qkv = torch.randn(B, N, 3 * D, device="cuda").to(torch.bfloat16)
 o = torch.empty(B, N, D, dtype=torch.bfloat16, device="cuda")
 lse = torch.empty(B, H, N, device="cuda")
 dO = torch.randn(B, N, D, device="cuda").to(torch.bfloat16)
+if os.environ.get("AB_ZERO"):  # DVFS probe: all-zero operands draw less power (cdna guide rule 25); compare against random data
+    qkv.zero_(); dO.zero_()
 dqkv = torch.empty_like(qkv)
 ws = torch.empty(2, B, H, N, device="cuda")
 p = lambda t: C.c_void_p(t.data_ptr())

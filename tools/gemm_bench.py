@@ -10,6 +10,8 @@ M, D = 64 * 1569, 384
 bf = torch.bfloat16
 torch.manual_seed(0)
 A = torch.randn(M, D, device="cuda").to(bf); A3 = torch.randn(M, 3 * D, device="cuda").to(bf); A4 = torch.randn(M, 4 * D, device="cuda").to(bf)
+if os.environ.get("GB_ZERO"):  # DVFS probe: all-zero operands (cdna guide rule 25)
+    A.zero_(); A3.zero_(); A4.zero_()
 cases = [("qkv        N1152 K384  bias", A, 3 * D, hip.EPI_BIAS_BF16), ("fc1        N1536 K384  bias+gelu", A, 4 * D, hip.EPI_BIAS_GELU_BF16),
          ("gelu-bwd   N1536 K384", A, 4 * D, hip.EPI_GELU_BWD_BF16), ("dgrad fc1T N384  K1536 plain", A4, D, hip.EPI_PLAIN_BF16),
          ("dgrad qkvT N384  K1152 plain", A3, D, hip.EPI_PLAIN_BF16), ("dgrad proj N384  K384  plain", A, D, hip.EPI_PLAIN_BF16)]
@@ -18,6 +20,8 @@ rounds = int(os.environ.get("GB_ROUNDS", 12))
 for name, a, N, epi in cases:
     K = a.shape[1]
     W = (torch.randn(N, K, device="cuda") * 0.05).to(bf)
+    if os.environ.get("GB_ZERO"):
+        W.zero_()
     bias = torch.zeros(N, device="cuda")
     out = torch.empty(M, N, dtype=bf, device="cuda")
     out2 = torch.empty(M, N, dtype=bf, device="cuda") if epi == hip.EPI_BIAS_GELU_BF16 else None
