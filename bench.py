@@ -168,9 +168,9 @@ def main():
     if use_dp:
         # RCCL's INIT log goes to a file (ONE JSON line on stdout): rank 0 parses the channel count actually set up from it
         rccl_log = f"/tmp/dcv_rccl_{os.getpid()}.log"
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ["NCCL_DEBUG"] = os.environ.get("DCV_NCCL_DEBUG", "INFO")  # DCV_NCCL_DEBUG=WARN switches the channel report off
         os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
-        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        os.environ["NCCL_DEBUG_FILE"] = rccl_log
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29655"
         from diverse_channel_vit_amd.dp import DataParallel as _DP
@@ -382,19 +382,22 @@ def main():
                           "buckets_per_step": round(dp.buckets_launched / max(steps_run, 1), 2),
                           "mbytes_reduced_per_step": round(dp.bytes_reduced / max(steps_run, 1) / 1e6, 2), "grad_dtype": args.grad_dtype,
                           "overlap": not args.no_overlap, "rccl_channels_requested": os.environ.get("NCCL_MAX_NCHANNELS"),
-                          "rccl_channels_in_use": dcv.DataParallel.rccl_channels_from_log(rccl_log) if rccl_log else None,
+                          "rccl_channels_in_use": None,  # filled in below, once the communicator is gone and its log complete
                           "reserved_cus": dp.reserved_cus}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.channels, args.img, args.classes)
-        print(json.dumps(line), flush=True)
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0 and rccl_log:
+            line["dp"]["rccl_channels_in_use"] = dcv.DataParallel.rccl_channels_from_log(rccl_log)
         if rccl_log:
             try:
                 os.remove(rccl_log)
             except OSError:
                 pass
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
