@@ -178,7 +178,8 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
     }
 }
 
-// gemm_nt geometry: 256 x 128 output tile, 8 waves as 4 (M) x 2 (N), each wave 64 x 64 = 2 x 2 MFMA 32x32x16 tiles.
+// gemm_nt geometry: 256 x 128 output tile, 8 waves as 4 (M) x 2 (N), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles
+// (same FLOPs per cycle as 32x32x16, but the power-limited chip clocks higher on it: NT GEMMs 3-9 % faster, profiles/r02_x4_*).
 // Measured on MI355X (tools/ab_bench.py ablations, M = 100 416, K = 384):
 //   * the main loop alone sustains ~965 TFLOP/s: operands arrive by LDS-DMA, whole 128-byte lines (8 rows x 128 B per
 //     instruction), K streamed in 64-wide stages through a 3-deep ring (two 48 KB stages always in flight);
@@ -218,17 +219,17 @@ __device__ __forceinline__ void nt_tile_setup(const GemmNtArgs& a, int L, int ti
     t.m0 = tm * NT_BM;
     t.n0 = tn * NT_BN;
     // one DMA instruction = 8 rows x 128 B (lane -> row lane>>3, physical chunk lane&7); the swizzle
-    // (physical chunk = logical ^ swz64(row)) is applied to the per-lane SOURCE chunk, the destination is linear.
+    // (physical chunk = logical ^ swz64n(row)) is applied to the per-lane SOURCE chunk, the destination is linear.
     // Wave w fills A rows [32w, 32w+32) (4 instructions) and W rows [16w, 16w+16) (2 instructions): 6 per stage.
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = 32 * wave + 8 * q + (lane >> 3);
-        t.gA[q] = a.A + (size_t)min(t.m0 + row, a.M - 1) * a.lda + (((lane & 7) ^ swz64(row)) * 8);
+        t.gA[q] = a.A + (size_t)min(t.m0 + row, a.M - 1) * a.lda + (((lane & 7) ^ swz64n(row)) * 8);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int row = 16 * wave + 8 * q + (lane >> 3);
-        t.gW[q] = a.W + (size_t)min(t.n0 + row, a.N - 1) * a.ldw + (((lane & 7) ^ swz64(row)) * 8);
+        t.gW[q] = a.W + (size_t)min(t.n0 + row, a.N - 1) * a.ldw + (((lane & 7) ^ swz64n(row)) * 8);
     }
 }
 
@@ -253,7 +254,6 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int h = lane >> 5, r32 = lane & 31;
     const int tiles_n = (a.N + NT_BN - 1) / NT_BN;
     const int tiles_m = (a.M + NT_BM - 1) / NT_BM;
     const int total = tiles_m * tiles_n;
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const unsigned dmaA = 32 * wave * 128, dmaW = NT_A_BYTES + 16 * wave * 128;  // wave-uniform byte offsets in a stage
     const int nk = a.K / NT_BK;
-    const int sw = swz64(r32);
-    const int rowA = (wm * 64 + r32) * 128, rowW = NT_A_BYTES + (wn * 64 + r32) * 128;
+    const int r16 = lane & 15, kg = lane >> 4;  // 16x16x32 fragments: row / column r16, k-chunk kg (8 elements)
+    const int rowA = (wm * 64 + r16) * 128, rowW = NT_A_BYTES + (wn * 64 + r16) * 128;  // + 16 i rows
     constexpr int EP_LD = 68;  // floats per slab row (272 B: 16-byte aligned, rows shifted by 4 banks)
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
 
@@ -295,13 +295,13 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = clock64();
 #endif
     for (;;) {
-        f32x16 acc[2][2];
+        f32x4 acc[4][4];  // wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
         for (int kt = 0; kt < nk; ++kt, ++g) {
             // Stage kt of this tile is complete once only YOUNGER operations of this wave are outstanding:
@@ -321,18 +321,18 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
             const char* st = smem + (g % NT_STAGES) * NT_STAGE_BYTES;
 #if DCV_GABL != 2
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int co = ((2 * ks + h) ^ sw) << 4;
-                bf16x8 af[2], wf[2];
+            for (int ks = 0; ks < 2; ++ks) {  // two k-steps of 32
+                bf16x8 af[4], wf[4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = as_bf16x8(lds_read128(st, rowA + i * 32 * 128 + co));
-                    wf[i] = as_bf16x8(lds_read128(st, rowW + i * 32 * 128 + co));
+                for (int i = 0; i < 4; ++i) {  // rows 16 i + r16 of the wave's A / W block: swz64n(16 i + r16) = ((r16 >> 1) & 7) for every i
+                    const int co = ((4 * ks + kg) ^ swz64n(r16)) << 4;
+                    af[i] = as_bf16x8(lds_read128(st, rowA + i * 16 * 128 + co));
+                    wf[i] = as_bf16x8(lds_read128(st, rowW + i * 16 * 128 + co));
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], wf[j], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], wf[j], acc[i][j]);
             }
 #else
             asm volatile("" ::"v"(st));
@@ -364,9 +364,9 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         }
 #if DCV_GABL == 1
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
         const bool full = false;
 #else
         // wave-private slab (16 rows x 64 cols f32) in the buffer consumed last; LDS operations of one wave execute in
@@ -374,12 +374,11 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         float* ep = reinterpret_cast<float*>(smem + ((g + NT_STAGES - 1) % NT_STAGES) * NT_STAGE_BYTES) + wave * 16 * EP_LD;
         const bool full = (cur.m0 + NT_BM <= a.M) && (cur.n0 + NT_BN <= a.N) && (EPI != DCV_EPI_PATCH);
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {  // quarter = 16 rows: block i = qt>>1, accumulator registers 8*(qt&1) .. +7
-            const int i = qt >> 1, rb = 8 * (qt & 1);
+        for (int qt = 0; qt < 4; ++qt) {  // quarter = the 16 rows of MFMA row block qt: lane (r16, kg) holds rows 4 kg .. +3 of column 16 j + r16
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + r32] = acc[i][j][rb + r];
+                for (int r = 0; r < 4; ++r) ep[(4 * kg + r) * EP_LD + j * 16 + r16] = acc[qt][j][r];
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) {  // 16 rows x 8 chunks = 128 items = 2 passes
                 const int row = ps * 8 + erow;
@@ -418,13 +417,13 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
 // Why: the 256 x 128 kernel is bound by operand delivery into LDS (34-37 GB/s per CU sustained, whatever the epilogue), so
 // its main-loop time scales with operand BYTES: (256+128)*2 B per 256*128*2 FLOP and k = 85 FLOP/B.  256 x 384 moves
 // (256+384)*2 B per 256*384*2 FLOP = 154 FLOP/B, 1.8x fewer bytes per FLOP.  Cost: 192 accumulator registers per lane
-// (8 waves as 4 (M) x 2 (N), each 64 x 192 = 2 x 6 MFMA tiles; they live in AGPRs, the loop needs ~40 arch VGPRs) and the
+// (8 waves as 4 (M) x 2 (N), each 64 x 192 = 4 x 12 MFMA 16x16x32 tiles; the k-step's read / MFMA order is pinned, see the loop) and the
 // whole LDS: two 80 KB stages.  With two buffers the next stage is issued after the barrier that retires the previous
 // one, one k-iteration (48 MFMAs per wave) ahead.  Tile walk, slab epilogue and fused ops as in gemm_nt_kernel.
 constexpr int N3_BM = 256, N3_BN = 384, N3_BK = 64;
 constexpr int N3_A_BYTES = N3_BM * N3_BK * 2, N3_W_BYTES = N3_BN * N3_BK * 2, N3_STAGE_BYTES = N3_A_BYTES + N3_W_BYTES;  // 80 KB
 constexpr int N3_SMEM = 2 * N3_STAGE_BYTES;                                                                              // 160 KB
-constexpr int N3_DMA = 10;  // per wave and stage: A rows [32w, 32w+32) = 4 pieces, W rows [48w, 48w+48) = 6 pieces
+// per wave and stage 10 DMA instructions: A rows [32w, 32w+32) = 4 pieces, W rows [48w, 48w+48) = 6 pieces
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
@@ -436,7 +435,6 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int h = lane >> 5, r32 = lane & 31;
     const int tiles_n = a.N / N3_BN;
     const int tiles_m = (a.M + N3_BM - 1) / N3_BM;
     const int total = tiles_m * tiles_n;
@@ -446,8 +444,8 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const unsigned dmaA = 32 * wave * 128, dmaW = N3_A_BYTES + 48 * wave * 128;  // wave-uniform byte offsets in a stage
     const int nk = a.K / N3_BK;
-    const int sw = swz64(r32);
-    const int rowA = (wm * 64 + r32) * 128, rowW = N3_A_BYTES + (wn * 192 + r32) * 128;
+    const int r16 = lane & 15, kg = lane >> 4;  // 16x16x32 fragments: row / column r16, k-chunk kg (8 elements)
+    const int rowA = (wm * 64 + r16) * 128, rowW = N3_A_BYTES + (wn * 192 + r16) * 128;  // + 16 i / 16 j rows
     constexpr int EP_LD = 68;
     const int erow = lane >> 3, ecol = (lane & 7) * 8;
 
@@ -457,12 +455,12 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = 32 * wave + 8 * q + (lane >> 3);
-        voffA[q] = (unsigned)(((size_t)row * a.lda + (((lane & 7) ^ swz64(row)) * 8)) * 2);
+        voffA[q] = (unsigned)(((size_t)row * a.lda + (((lane & 7) ^ swz64n(row)) * 8)) * 2);
     }
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
         const int row = 48 * wave + 8 * q + (lane >> 3);
-        voffW[q] = (unsigned)(((size_t)row * a.ldw + (((lane & 7) ^ swz64(row)) * 8)) * 2);
+        voffW[q] = (unsigned)(((size_t)row * a.ldw + (((lane & 7) ^ swz64n(row)) * 8)) * 2);
     }
     auto issue = [&](int m0_, int n0_, int kt, unsigned stage_base) {
         const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);  // uniform by construction
@@ -472,11 +470,15 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) glds16s(ab, voffA[q], stage_base + dmaA + q * 1024);
         } else {
+            // the lane id goes through an opaque move: otherwise hipcc hoists these offsets to the top of EVERY tile, spills
+            // them, and the reload's s_waitcnt vmcnt(0) there drains the previous tile's epilogue stores
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int row = 32 * wave + 8 * q + (lane >> 3);
+                const int row = 32 * wave + 8 * q + (ln >> 3);
                 const int rc = min(m0 + row, a.M - 1) - m0;
-                glds16s(ab, (unsigned)(((size_t)rc * a.lda + (((lane & 7) ^ swz64(row)) * 8)) * 2), stage_base + dmaA + q * 1024);
+                glds16s(ab, (unsigned)(((size_t)rc * a.lda + (((ln & 7) ^ swz64n(row)) * 8)) * 2), stage_base + dmaA + q * 1024);
             }
         }
 #pragma unroll
@@ -496,14 +498,15 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = clock64();
 #endif
     for (;;) {
-        f32x16 acc[2][6];
+        f32x4 acc[4][12];  // wave tile 64 x 192 = 4 x 12 MFMA tiles of 16 x 16
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
+            for (int j = 0; j < 12; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
+#pragma clang loop unroll(disable)  // also keeps hipcc from peeling the first iteration (the peeled copy spilled)
         for (int kt = 0; kt < nk; ++kt, ++g) {
             // stage kt landed once only younger operations are outstanding: for kt == 0 the previous tile's S epilogue
             // stores (issued after this tile's first stage); afterwards nothing of ours is younger than the stage
@@ -512,18 +515,27 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done with buffer (g+1)&1 (reads / slabs)
             if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
             const char* st = smem + (g & 1) * N3_STAGE_BYTES;
+            // 24 steps (2 k-steps of 32 x 12 column blocks) of 4 MFMAs; the W fragment of step s + 2 is read at step s (ring of 3),
+            // the 4 A fragments of the second k-step replace those of the first one by one behind their last MFMA.  The order
+            // is pinned (sched_barrier): left alone, hipcc hoists all 16 reads of a k-step and spills accumulators (192 of the
+            // 256 registers a wave has at 8 waves per workgroup are accumulators).
+            const int co0 = (kg ^ swz64n(r16)) << 4;  // k-step 0: chunk kg; k-step 1: chunk 4 + kg = co0 ^ 64.  swz64n(16 i + r16) is the same for every i
+            auto rdW = [&](int s2) { return as_bf16x8(lds_read128(st, rowW + (s2 % 12) * 16 * 128 + (co0 ^ (s2 >= 12 ? 64 : 0)))); };
+            bf16x8 af[4], wq[3];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int co = ((2 * ks + h) ^ sw) << 4;
-                bf16x8 af[2];
+            for (int i = 0; i < 4; ++i) af[i] = as_bf16x8(lds_read128(st, rowA + i * 16 * 128 + co0));
+            wq[0] = rdW(0);
+            wq[1] = rdW(1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[i] = as_bf16x8(lds_read128(st, rowA + i * 32 * 128 + co));
+            for (int s2 = 0; s2 < 24; ++s2) {
+                if (s2 + 2 < 24) wq[(s2 + 2) % 3] = rdW(s2 + 2);
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const bf16x8 wf = as_bf16x8(lds_read128(st, rowW + j * 32 * 128 + co));
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) acc[i][j] = mfma32(af[i], wf, acc[i][j]);
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][s2 % 12] = mfma16(af[i], wq[s2 % 3], acc[i][s2 % 12]);
+                    if (s2 == 11) af[i] = as_bf16x8(lds_read128(st, rowA + i * 16 * 128 + (co0 ^ 64)));
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: buffer (g-1)&1 now holds the slabs
@@ -547,8 +559,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             float bz[8];
             if constexpr (HAS_BIAS) load8_f32(a.bias + nn, bz);
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {  // quarter = 16 rows: block i = qt>>1, accumulator registers 8*(qt&1) .. +7
-                const int i = qt >> 1, rb = 8 * (qt & 1);
+            for (int qt = 0; qt < 4; ++qt) {  // quarter = the 16 rows of MFMA row block qt: lane (r16, kg) holds rows 4 kg .. +3
                 constexpr bool AUX_EARLY = HAS_AUX;  // the auxiliary rows of both passes are loaded before the slab round trip
                 float x[AUX_EARLY ? 2 : 1][8];
                 if constexpr (AUX_EARLY) {
@@ -556,10 +567,9 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
                     for (int ps = 0; ps < 2; ++ps) epi_aux8<EPI>(a, min(mbase + (qt * 2 + ps) * 8 + erow, a.M - 1), nn, x[ps]);
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        ep[((r & 3) + 8 * (r >> 2) + 4 * h) * EP_LD + j * 32 + r32] = acc[i][2 * cg + j][rb + r];
+                    for (int r = 0; r < 4; ++r) ep[(4 * kg + r) * EP_LD + j * 16 + r16] = acc[qt][4 * cg + j][r];
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps) {
                     const int row = ps * 8 + erow;
