@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--force-dp", action="store_true", help="exercise the N>1 code path on one GPU: RCCL group of world size 1, collectives forced")
     ap.add_argument("--grad-dtype", default="float32", choices=["float32", "bfloat16"], help="N>1: dtype the gradient buckets travel in")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: one all-reduce after the backward instead of per-layer buckets beside it")
+    ap.add_argument("--wgrad-stream", type=int, default=None, choices=[0, 1], help="weight-gradient GEMMs on a second HIP stream (default: the model's default)")
     ap.add_argument("--hcs", action="store_true", help="secondary run (SURVEY §8d): enable_sample=True, hcs_sampling=lowest_cosine_prob, temp 1000 "
                                                      "(variable sequence length, one host sync per step like the reference)")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant (never the headline value): every step's batch comes from pinned "
@@ -189,6 +190,8 @@ def main():
         torch.manual_seed(33978 + 21022023)
     torch.manual_seed(0)
     model = dcv.dichavit(cfg, mapper={"train": list(range(args.channels))}).to(dev)
+    if args.wgrad_stream is not None:
+        model.wgrad_stream = bool(args.wgrad_stream)
     model.train()
     dp = None
     if use_dp:  # INTEGRATION.md's call order: wrap, equalise, hook — all before the first forward
@@ -372,6 +375,7 @@ def main():
                        "input": ("pinned host memory -> HBM every step (copy stream, double-buffered)" if args.h2d else "resident in HBM"),
                        "host_syncs_per_step": 0,
                        "launch": "hip-graph replay of the captured step" if use_graph else "eager",
+                       "wgrad_stream": bool(model.wgrad_stream),
                        **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)"} if args.hcs else {})},
             "roofline": roof,
             "kernel_table": table[:24],

@@ -250,6 +250,8 @@ class DiChaViT(nn.Module):
         self._arena = None
         self._grad_arena = None
         self._dp = None  # set by diverse_channel_vit_amd.dp.DataParallel
+        self.wgrad_stream = True  # the backward runs the weight-gradient GEMMs on a second HIP stream (_run_backward_body); False: one stream
+        self._side = None
         self._R_cache: Dict = {}
         self._idx_cache: Dict = {}
         self.hcs_sampler = None  # optional callable(model, chunk_name, cur_channels) -> (picked ids, positions): pins the subset
@@ -685,16 +687,59 @@ class DiChaViT(nn.Module):
         dO = torch.empty(M, D, dtype=bf, device=dev)
         dqkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
         delta = torch.empty(2, B, H, N, dtype=f32, device=dev)  # attention backward workspace: -delta, lse*log2e
+        # Weight-gradient products on a second stream (self.wgrad_stream): nothing in the backward depends on them, so their
+        # workgroups fill the tail of the input-gradient / attention kernels and their atomic flush overlaps the next kernel.
+        # Hazards are the scratch buffers they read (dxb, dz, dqkv: the main stream waits for the last side-stream reader
+        # before it overwrites one; dxb alternates between two buffers so that wait is never a stall) and the saved activations
+        # (held until the streams have joined).
+        main = torch.cuda.current_stream(dev)
+        side_all = self._side_stream(dev) if self.wgrad_stream else None
+        side = None  # per layer: the CLS-only last block keeps its (tiny) products on the main stream
+        readers, held = {}, []
+
+        def wgrad(Y, X, gw, gb, key):
+            if side is None:
+                hip.gemm_tn_acc(Y, X, gw, gb)
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                hip.gemm_tn_acc(Y, X, gw, gb)
+                done = torch.cuda.Event()
+                done.record(side)
+            readers[key] = done
+
+        def before_write(key):
+            ev = readers.pop(key, None)
+            if ev is not None:
+                main.wait_event(ev)
+
+        def join():
+            if side_all is not None:
+                ev = torch.cuda.Event()
+                ev.record(side_all)
+                main.wait_event(ev)
+                readers.clear()
+
+        dxb_alt = None
         for li in range(len(fe.blocks) - 1, -1, -1):
             blk, L = fe.blocks[li], st["layers"][li]
             tail = L["tail"]
+            side = None if tail else side_all
+            if side is not None and (dxb_alt is None or dxb_alt.shape != dxb.shape):
+                dxb_alt = torch.empty_like(dxb)
             R = B if tail else M
             dz_, du_ = (dz[:R], du[:R]) if tail else (dz, du)
             # MLP
+            before_write("dz")
             hip.gemm_nt(dxb, self._bf(blk.mlp.fc2.weight, True), hip.EPI_GELU_BWD_BF16, dz_, aux=L["z"], **nt_kw)
-            hip.gemm_tn_acc(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias))
+            wgrad(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias), id(dxb))
             hip.gemm_nt(dz_, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du_, **nt_kw)
-            hip.gemm_tn_acc(dz_, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias))
+            wgrad(dz_, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias), "dz")
+            if side is not None:
+                dxb, dxb_alt = dxb_alt, dxb  # the fc2 weight gradient may still be reading the old one
+            before_write(id(dxb))
             hip.ln_bwd(du_, L["x_mid"], L["mean2"], L["rstd2"], blk.norm2.weight, dx, dx, dxb, g(blk.norm2.weight), g(blk.norm2.bias), R, D)
             # attention
             if tail:
@@ -709,14 +754,23 @@ class DiChaViT(nn.Module):
                 dxb = torch.empty(M, D, dtype=bf, device=dev)
             else:
                 hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO, **nt_kw)
-                hip.gemm_tn_acc(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias))
+                wgrad(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias), id(dxb))
+                before_write("dqkv")
                 hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
             hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du, **nt_kw)
-            hip.gemm_tn_acc(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias))
+            wgrad(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv")
+            if side is not None:
+                dxb, dxb_alt = dxb_alt, dxb
+            before_write(id(dxb))
             hip.ln_bwd(du, L["x_in"], L["mean1"], L["rstd1"], blk.norm1.weight, dx, dx, dxb, g(blk.norm1.weight), g(blk.norm1.bias), M, D)
+            if side is not None:
+                held.append(dict(L))  # the side stream may still be reading the saved activations
             L.clear()
             if dp is not None:
+                join()  # the all-reduce is ordered after the main stream only
                 dp.grad_ready(ga, *self._range_of([blk.norm1.weight, blk.mlp.fc2.bias]))
+        join()
+        held.clear()
         # --- tokeniser ---
         if st.get("keep_dev") is not None:  # adjoint of the token gather: dropped tokens receive no gradient
             Nf = st["N_full"]
@@ -741,6 +795,11 @@ class DiChaViT(nn.Module):
         for p in self._enc_params:
             grads.append(self._gview(ga, p) if p.requires_grad else None)
         return dE, dpos, grads
+
+    def _side_stream(self, dev):
+        if self._side is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)  # same priority as the main stream: a high-priority side stream measured no better
+        return self._side
 
     def _range_of(self, ps):
         """[start, end) of the arena slots between the first and the last parameter given (inclusive)."""

@@ -906,3 +906,31 @@ def test_dp_two_ranks_real_model_two_backwards(gpu_device):
         if rank == 0:
             print(f"two ranks, two backward passes: worst relative gradient difference vs single-process sum {worst:.2e}")
             assert worst <= 2e-3  # fp32 atomic ordering noise of the weight-gradient GEMMs only
+
+
+def test_weight_gradients_on_second_stream_match_one_stream(gpu_device):
+    """The backward runs the weight-gradient GEMMs on a second HIP stream (dichavit.py, _run_backward_body: wgrad_stream).  Same
+    kernels on the same operands as the one-stream backward: every gradient must agree up to the order of the fp32 atomic adds of
+    the split reductions (each launch's own order is not fixed either), over several steps (the scratch buffers the side stream
+    reads are reused every layer and every step) and against the fp64 oracle."""
+    meta, a = load_golden("so2sat_s")
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], meta["C_in"], meta["img"], meta["num_classes"])
+    grads = {}
+    for mode in (True, False):
+        model, _ = build(meta, gpu_device)
+        model.wgrad_stream = mode
+        for _ in range(3):  # repeated backward passes: same result every time
+            model.zero_grad(set_to_none=True)
+            out, extra = model(x.to(gpu_device), meta["chunk"], None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            (torch.nn.CrossEntropyLoss()(out, y.to(gpu_device)) + extra).backward()
+        torch.cuda.synchronize()
+        grads[mode] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        if mode:
+            ch = meta["mapper"][meta["chunk"]]
+            sd_ref, *_ = oracle_grads(meta, x, y, ch, list(range(len(ch))))
+            check_grads(model, sd_ref)
+    assert grads[True].keys() == grads[False].keys()
+    for n, g in grads[True].items():
+        ref = grads[False][n]
+        err = (g - ref).abs().max().item()
+        assert err <= 1e-5 * ref.abs().max().item() + 1e-9, (n, err, ref.abs().max().item())
