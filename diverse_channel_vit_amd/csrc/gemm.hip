@@ -46,6 +46,29 @@ __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& e) {
     const float erf_abs = 1.0f - poly * e;
     cdf = 0.5f * (1.0f + copysignf(erf_abs, z));
 }
+#ifndef DCV_GELU_PK
+#define DCV_GELU_PK 1  // fc1 epilogue on two elements at a time: 225-227 us against 232-243 (profiles/r02_x8_*); 0 = the scalar form
+#endif
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// the same arithmetic on two elements at a time (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32; rcp and exp2 stay scalar)
+__device__ __forceinline__ void gelu_parts2(f32x2_t z, f32x2_t& g, f32x2_t& gp) {
+    f32x2_t ax = {fabsf(z.x), fabsf(z.y)};
+    const f32x2_t d = ax * 0.23164189f + 1.0f;  // 1 + 0.3275911 |z| / sqrt 2
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f32x2_t zz = z * z * -0.72134752044448170f;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(zz.x), __builtin_amdgcn_exp2f(zz.y)};
+    f32x2_t poly = t * 1.061405429f + -1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + -0.284496736f;
+    poly = poly * t + 0.254829592f;
+    poly = poly * t;
+    const f32x2_t h = poly * e * -0.5f + 0.5f;  // 0.5 erfc-part: cdf(|z|) - 0.5 = 0.5 - 0.5 poly e
+    // cdf(z) = 0.5 + sign(z) * h
+    const f32x2_t sh = {copysignf(h.x, z.x), copysignf(h.y, z.y)};
+    const f32x2_t cdf = sh + 0.5f;
+    g = z * cdf;
+    gp = z * e * 0.39894228040143268f + cdf;
+}
 __device__ __forceinline__ uint4 pack8_bf16(const float* v) {
     uint2 lo = pack4_bf16(v[0], v[1], v[2], v[3]), hi = pack4_bf16(v[4], v[5], v[6], v[7]);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -143,6 +166,16 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
         // out = GELU'(z), out2 = GELU(z), z = acc + bias in fp32: the backward then only multiplies (the first version saved z
         // and recomputed the erf / exp in the backward epilogue, ~45 % of that kernel's time); cdf and exp(-z^2/2) are shared
         float gp[8];
+#if DCV_GELU_PK
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const f32x2_t z = {v[e] + bz[e], v[e + 1] + bz[e + 1]};
+            f32x2_t g2, gp2;
+            gelu_parts2(z, g2, gp2);
+            v[e] = g2.x; v[e + 1] = g2.y;
+            gp[e] = gp2.x; gp[e + 1] = gp2.y;
+        }
+#else
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float z = v[e] + bz[e];
@@ -151,6 +184,7 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
             v[e] = z * cdf;
             gp[e] = cdf + z * 0.39894228040143268f * ex;
         }
+#endif
         st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(gp));
         st128_stream((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
