@@ -232,6 +232,9 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
 #ifndef DCV_GABL
 #define DCV_GABL 0  // timing-only ablations: 1 = no epilogue, 2 = no MFMA/LDS reads, 3 = no operand DMA
 #endif
+#ifndef DCV_DMA_SPLIT
+#define DCV_DMA_SPLIT 1  // gemm_nt_kernel: the two waves of a SIMD issue their DMA pieces at different points of a stage (0: all at the top)
+#endif
 constexpr int NT_BM = 256, NT_BN = 128, NT_BK = 64, NT_STAGES = 3;
 constexpr int NT_A_BYTES = NT_BM * NT_BK * 2, NT_W_BYTES = NT_BN * NT_BK * 2, NT_STAGE_BYTES = NT_A_BYTES + NT_W_BYTES;  // 48 KB
 constexpr int NT_SMEM = NT_STAGES * NT_STAGE_BYTES;  // the ring (epilogue slabs alias the stage consumed last)
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const bool late = (wave >> 2) != 0;  // waves w and w + 4 share a SIMD
     const int tiles_n = (a.N + NT_BN - 1) / NT_BN;
     const int tiles_m = (a.M + NT_BM - 1) / NT_BM;
     const int total = tiles_m * tiles_n;
@@ -351,11 +355,26 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();  // everyone's stage g landed; everyone is done with buffer (g-1)%3 (reads and slabs)
+#if DCV_DMA_SPLIT
+            // The two waves of a SIMD (w and w + 4) issue their 6 DMA pieces at different times — one at the top of the stage, the
+            // other between its two k-steps — so that one of them is always feeding the matrix pipe (a piece costs 60-180 issue cycles,
+            // six of them about as much as the stage's 32 MFMAs): -4 .. -7 % on every shape (profiles/r02_x10_*).  The per-wave issue
+            // ORDER is unchanged, so the counted vmcnt waits hold; the ring is three deep, the late pieces still have a full stage to land.
+            if (!late && kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+#else
             if (kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+#endif
             const char* st = smem + (g % NT_STAGES) * NT_STAGE_BYTES;
 #if DCV_GABL != 2
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {  // two k-steps of 32
+#if DCV_DMA_SPLIT
+                if (ks == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (late && kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#endif
                 bf16x8 af[4], wf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {  // rows 16 i + r16 of the wave's A / W block: swz64n(16 i + r16) = ((r16 >> 1) & 7) for every i
@@ -547,6 +566,8 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             if (kt == 0 && stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done with buffer (g+1)&1 (reads / slabs)
+            // (issuing half the waves' pieces between the two k-steps, as gemm_nt_kernel does, measured 3-5 % slower here: with two
+            // stages the late pieces have half a stage to land)
             if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
             const char* st = smem + (g & 1) * N3_STAGE_BYTES;
             // 24 steps (2 k-steps of 32 x 12 column blocks) of 4 MFMAs; the W fragment of step s + 2 is read at step s (ring of 3),
@@ -877,7 +898,7 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + T3_STAGES - 1 < nk) T3_ISSUE(kt + T3_STAGES - 1)
+        if (kt + T3_STAGES - 1 < nk) T3_ISSUE(kt + T3_STAGES - 1)  // (split between the SIMD partners as in gemm_nt_kernel: +-1 %, not kept)
         char* st = smem + (kt % T3_STAGES) * T3_STAGE_BYTES;
         if (kt == nk - 1 && last_valid < T3_BK) {  // ragged end of the reduction: rows that do not exist must contribute 0
             const int nbad = T3_BK - last_valid;
