@@ -1016,7 +1016,7 @@ extern "C" int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile) {
     const bool legal384 = (N % N3_BN) == 0 && epilogue != DCV_EPI_PATCH;
     if (tile == DCV_TILE_WIDE) return legal384 ? DCV_TILE_WIDE : DCV_ERR_UNSUPPORTED;
     if (tile == DCV_TILE_NARROW) return DCV_TILE_NARROW;
-    return (legal384 && M >= 4096 && (N >= 1152 || K >= 1152) && epilogue != DCV_EPI_GELU_BWD_BF16) ? DCV_TILE_WIDE : DCV_TILE_NARROW;
+    return (legal384 && M >= 4096 && (N >= 1152 || K >= 1536) && epilogue != DCV_EPI_GELU_BWD_BF16) ? DCV_TILE_WIDE : DCV_TILE_NARROW;
 }
 
 extern "C" int dcv_gemm_tn_pick(int M, int P, int Q, int tile) {

@@ -55,3 +55,29 @@ def test_product_never_imports_oracle():
         if f.endswith(".py"):
             txt = open(os.path.join(pkg, f)).read()
             assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_gemm_tile_choice_rules():
+    """dcv_gemm_nt_pick / dcv_gemm_tn_pick are host logic (no GPU call): the automatic tile choice for the headline step's products
+    (measured per shape in profiles/r02_x4_* and r02_x10_*) and the refusal of an illegal forced tile."""
+    from diverse_channel_vit_amd import hip
+    lib = hip.load()
+    M = 64 * 1569
+    A, N_, W = hip.TILE_AUTO, hip.TILE_NARROW, hip.TILE_WIDE
+    nt = lambda m, n, k, epi, t=A: lib.dcv_gemm_nt_pick(m, n, k, epi, t)
+    assert nt(M, 1152, 384, hip.EPI_BIAS_BF16) == W            # qkv
+    assert nt(M, 1536, 384, hip.EPI_BIAS_GELU_BF16) == W       # fc1 + GELU
+    assert nt(M, 1536, 384, hip.EPI_GELU_BWD_BF16) == N_       # GELU backward: 616 MB of epilogue traffic, narrow is faster
+    assert nt(M, 384, 1536, hip.EPI_BIAS_RESID_F32) == W       # fc2 + residual
+    assert nt(M, 384, 1536, hip.EPI_PLAIN_BF16) == W           # input gradient of fc1
+    assert nt(M, 384, 1152, hip.EPI_PLAIN_BF16) == N_          # input gradient of qkv
+    assert nt(M, 384, 384, hip.EPI_BIAS_RESID_F32) == N_       # proj
+    assert nt(64, 1536, 384, hip.EPI_BIAS_GELU_BF16) == N_     # the CLS-only last block
+    assert nt(M, 200, 384, hip.EPI_PLAIN_BF16) == N_           # N % 384 != 0
+    assert nt(M, 384, 256, hip.EPI_PATCH) == N_                # the tokeniser epilogue lives on the narrow kernel only
+    assert nt(M, 200, 384, hip.EPI_PLAIN_BF16, W) < 0 and nt(M, 384, 256, hip.EPI_PATCH, W) < 0 and nt(M, 384, 384, 0, 7) < 0
+    assert nt(M, 1152, 384, hip.EPI_BIAS_BF16, N_) == N_ and nt(M, 384, 384, hip.EPI_PLAIN_BF16, W) == W
+    tn = lambda p, q, t=A: lib.dcv_gemm_tn_pick(M, p, q, t)
+    assert tn(384, 1536) == W and tn(1536, 384) == W and tn(1152, 384) == W
+    assert tn(384, 384) == N_ and tn(384, 256) == N_ and tn(200, 128) == N_
+    assert tn(200, 128, W) < 0 and tn(384, 384, W) == W and tn(384, 1536, N_) == N_
