@@ -232,6 +232,9 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
 #ifndef DCV_GABL
 #define DCV_GABL 0  // timing-only ablations: 1 = no epilogue, 2 = no MFMA/LDS reads, 3 = no operand DMA
 #endif
+#ifndef DCV_READ_FIRST
+#define DCV_READ_FIRST 1  // gemm_nt384_kernel: a stage's first fragment reads are issued BEFORE the next stage's ten DMA pieces (-2 %; the narrow kernel and gemm_tn384 measured slower / equal with it)
+#endif
 #ifndef DCV_DMA_SPLIT
 #define DCV_DMA_SPLIT 1  // gemm_nt_kernel: the two waves of a SIMD issue their DMA pieces at different points of a stage (0: all at the top)
 #endif
@@ -568,7 +571,9 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done with buffer (g+1)&1 (reads / slabs)
             // (issuing half the waves' pieces between the two k-steps, as gemm_nt_kernel does, measured 3-5 % slower here: with two
             // stages the late pieces have half a stage to land)
+#if !DCV_READ_FIRST
             if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
+#endif
             const char* st = smem + (g & 1) * N3_STAGE_BYTES;
             // 24 steps (2 k-steps of 32 x 12 column blocks) of 4 MFMAs; the W fragment of step s + 2 is read at step s (ring of 3),
             // the 4 A fragments of the second k-step replace those of the first one by one behind their last MFMA.  The order
@@ -582,6 +587,10 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             wq[0] = rdW(0);
             wq[1] = rdW(1);
             __builtin_amdgcn_sched_barrier(0);
+#if DCV_READ_FIRST
+            if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int s2 = 0; s2 < 24; ++s2) {
                 if (s2 + 2 < 24) wq[(s2 + 2) % 3] = rdW(s2 + 2);
@@ -898,7 +907,7 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + T3_STAGES - 1 < nk) T3_ISSUE(kt + T3_STAGES - 1)  // (split between the SIMD partners as in gemm_nt_kernel: +-1 %, not kept)
+        if (kt + T3_STAGES - 1 < nk) T3_ISSUE(kt + T3_STAGES - 1)  // (split between the SIMD partners as in gemm_nt_kernel, or issued behind the first fragment reads: +-1 %, not kept)
         char* st = smem + (kt % T3_STAGES) * T3_STAGE_BYTES;
         if (kt == nk - 1 && last_valid < T3_BK) {  // ragged end of the reduction: rows that do not exist must contribute 0
             const int nbad = T3_BK - last_valid;
