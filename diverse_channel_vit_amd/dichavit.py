@@ -767,8 +767,17 @@ class DiChaViT(nn.Module):
                 held.append(dict(L))  # the side stream may still be reading the saved activations
             L.clear()
             if dp is not None:
-                join()  # the all-reduce is ordered after the main stream only
-                dp.grad_ready(ga, *self._range_of([blk.norm1.weight, blk.mlp.fc2.bias]))
+                if side is not None:
+                    # hand the bucket over FROM the side stream: the collective is ordered after the stream it is issued on, and the
+                    # side stream — made to wait for this layer's last LayerNorm-backward on the main stream — is behind every writer
+                    # of the slice; the main stream itself never waits for the weight gradients here
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        dp.grad_ready(ga, *self._range_of([blk.norm1.weight, blk.mlp.fc2.bias]))
+                else:
+                    dp.grad_ready(ga, *self._range_of([blk.norm1.weight, blk.mlp.fc2.bias]))
         join()
         held.clear()
         # --- tokeniser ---

@@ -169,6 +169,8 @@ class DataParallel:
                 buf.mul_(1.0 / self.world)
             if dst is not None:
                 dst.copy_(buf)
+                if buf.is_cuda:  # buf may have been allocated while another stream was current (the model's weight-gradient stream)
+                    buf.record_stream(torch.cuda.current_stream(buf.device))
         self._works.clear()
 
     def finalize(self) -> None:
