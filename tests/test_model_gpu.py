@@ -376,6 +376,10 @@ def test_dp_reducer_on_rccl_single_gpu(gpu_device):
         for k, g in grads["plain"].items():
             ref = g.abs().max().item()
             assert (grads["dp"][k] - g).abs().max().item() <= 1e-3 * ref + 1e-9, k
+        # and against the checker: every gradient that went through RCCL vs the fp64 oracle on the same batch
+        ch = meta["mapper"][meta["chunk"]]
+        sd_ref, *_ = oracle_grads(meta, x.cpu(), y.cpu(), ch, list(range(len(ch))))
+        check_grads(model, sd_ref)
     finally:
         dist.destroy_process_group()
 
@@ -481,6 +485,17 @@ def test_fused_input_normalisation(gpu_device):
     assert (f0 - f1).abs().max().item() <= 2e-2 * f0.abs().max().item()
     assert abs(e0 - e1) <= 1e-3 * abs(e0) + 1e-6
     assert (g0 - g1).norm().item() <= 2e-2 * g0.norm().item()
+    # and against the checker: the fp64 oracle fed the batch the reference would see (normalised on the host)
+    shapes = orc.state_shapes(meta["cfg"], 12, meta["img"], meta["num_classes"], chammi=True)
+    sd = orc.make_state(shapes, meta["seed"], dtype=torch.float64)
+    for v in sd.values():
+        v.requires_grad_(True)
+    fr, er = orc.forward(sd, ref_in.double(), meta["cfg"], ch, list(range(len(ch))))
+    (fr.square().mean() + er).backward()
+    assert (f1.double().cpu() - fr.detach()).abs().max().item() <= 3e-2 * fr.detach().abs().max().item()
+    assert abs(e1 - er.item()) <= 2e-2 * abs(er.item()) + 1e-6
+    gr = sd["feature_extractor.patch_embed.proj.weight"].grad
+    assert (g1.double().cpu() - gr).norm().item() <= 5e-2 * gr.norm().item()
     model, _ = build(meta, gpu_device)
     with pytest.raises(ValueError):
         model(raw.to(gpu_device), "HPA")
