@@ -14,7 +14,8 @@ if os.environ.get("GB_ZERO"):  # DVFS probe: all-zero operands (cdna guide rule 
     A.zero_(); A3.zero_(); A4.zero_()
 cases = [("qkv        N1152 K384  bias", A, 3 * D, hip.EPI_BIAS_BF16), ("fc1        N1536 K384  bias+gelu", A, 4 * D, hip.EPI_BIAS_GELU_BF16),
          ("gelu-bwd   N1536 K384", A, 4 * D, hip.EPI_GELU_BWD_BF16), ("dgrad fc1T N384  K1536 plain", A4, D, hip.EPI_PLAIN_BF16),
-         ("dgrad qkvT N384  K1152 plain", A3, D, hip.EPI_PLAIN_BF16), ("dgrad proj N384  K384  plain", A, D, hip.EPI_PLAIN_BF16)]
+         ("dgrad qkvT N384  K1152 plain", A3, D, hip.EPI_PLAIN_BF16), ("dgrad proj N384  K384  plain", A, D, hip.EPI_PLAIN_BF16),
+         ("fc2        N384  K1536 bias+resid", A4, D, hip.EPI_BIAS_RESID_F32), ("proj       N384  K384  bias+resid", A, D, hip.EPI_BIAS_RESID_F32)]
 names = {hip.TILE_NARROW: "narrow", hip.TILE_WIDE: "wide"}
 rounds = int(os.environ.get("GB_ROUNDS", 12))
 for name, a, N, epi in cases:
@@ -23,9 +24,9 @@ for name, a, N, epi in cases:
     if os.environ.get("GB_ZERO"):
         W.zero_()
     bias = torch.zeros(N, device="cuda")
-    out = torch.empty(M, N, dtype=bf, device="cuda")
+    out = torch.empty(M, N, dtype=torch.float32 if epi == hip.EPI_BIAS_RESID_F32 else bf, device="cuda")
     out2 = torch.empty(M, N, dtype=bf, device="cuda") if epi == hip.EPI_BIAS_GELU_BF16 else None
-    aux = torch.randn(M, N, device="cuda").to(bf) if epi == hip.EPI_GELU_BWD_BF16 else None
+    aux = torch.randn(M, N, device="cuda").to(bf) if epi == hip.EPI_GELU_BWD_BF16 else (torch.randn(M, N, device="cuda") if epi == hip.EPI_BIAS_RESID_F32 else None)
     res = {t: [] for t in names}
     for rnd in range(rounds):
         for t in names:
