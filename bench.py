@@ -297,6 +297,7 @@ def main():
             consumed[slot].record()
             return loss
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    picks0 = sum(model.feature_extractor.patch_embed.counter.values()) if args.hcs else 0  # channel draws so far (HCS histogram)
     sync()
     t0 = time.perf_counter()
     marks[0].record()
@@ -396,7 +397,12 @@ def main():
                        "host_syncs_per_step": 0,
                        "launch": "hip-graph replay of the captured step" if use_graph else "eager",
                        "wgrad_stream": bool(model.wgrad_stream),
-                       **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)"} if args.hcs else {})},
+                       **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)",
+                           # the secondary run reports tokens/s too.  Tokens of a step = batch * (1 + C_step * n); the sum of
+                           # C_step over the timed steps is the growth of the model's channel histogram (patch_embed.counter)
+                           "channels_per_step": round((sum(model.feature_extractor.patch_embed.counter.values()) - picks0) / args.steps, 2),
+                           "tokens_per_sec": round(args.batch * world * (args.steps + n * (sum(model.feature_extractor.patch_embed.counter.values()) - picks0)) / dt, 1)}
+                          if args.hcs else {})},
             "roofline": roof,
             "kernel_table_mode": "per-launch durations from the profiled warm-up steps, run on one stream (exclusive); "
                                  "ms_per_step and share_of_step refer to that one-stream step",
