@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--wgrad-stream", type=int, default=None, choices=[0, 1], help="weight-gradient GEMMs on a second HIP stream (default: the model's default)")
     ap.add_argument("--hcs", action="store_true", help="secondary run (SURVEY §8d): enable_sample=True, hcs_sampling=lowest_cosine_prob, temp 1000 "
                                                      "(variable sequence length, one host sync per step like the reference)")
+    ap.add_argument("--chammi", action="store_true", help="secondary run (SURVEY §8d, BASELINE config 3): the CHAMMI step of trainer.py:846-935 — a 12-channel "
+                                                        "model, the batch split into Allen / HPA / CP sub-batches of 3 / 4 / 5 channels, proxy main loss on the "
+                                                        "features, three forward/backward passes accumulate into one optimiser step")
     ap.add_argument("--h2d", action="store_true", help="PCIe-inclusive variant (never the headline value): every step's batch comes from pinned "
                                                      "host memory through a copy stream, double-buffered against the previous step")
     args = ap.parse_args()
@@ -182,6 +185,8 @@ def main():
     from diverse_channel_vit_amd import hip
     hip.load()
 
+    if args.chammi:
+        args.channels, args.classes = 12, 14
     cfg = model_cfg(args.arch, args.channels, args.img, 16, args.classes)
     if args.hcs:
         cfg.update(enable_sample=True, hcs_sampling="lowest_cosine_prob", hcs_sampling_temp=1000.0)
@@ -189,7 +194,8 @@ def main():
         random.seed(33978 + 21022023)  # same seed on every rank (dataset_utils.py:589): ranks draw the same subset
         torch.manual_seed(33978 + 21022023)
     torch.manual_seed(0)
-    model = dcv.dichavit(cfg, mapper={"train": list(range(args.channels))}).to(dev)
+    chammi_map = {"Allen": [0, 1, 2], "HPA": [3, 4, 5, 6], "CP": [7, 8, 9, 10, 11]}  # trainer.py:130-131
+    model = dcv.dichavit(cfg, mapper=chammi_map if args.chammi else {"train": list(range(args.channels))}).to(dev)
     if args.wgrad_stream is not None:
         model.wgrad_stream = bool(args.wgrad_stream)
     model.train()
@@ -198,7 +204,7 @@ def main():
         dp = dcv.DataParallel(model, force_collectives=args.force_dp, grad_dtype=getattr(torch, args.grad_dtype), overlap=not args.no_overlap)
         dp.broadcast_parameters(0)
         dp.hook_misc_params()
-    use_graph = args.graph and (world == 1) and not use_dp and not args.hcs
+    use_graph = args.graph and (world == 1) and not use_dp and not args.hcs and not args.chammi
     opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=4.9e-5, betas=(0.9, 0.999), eps=1e-8,
                        weight_decay=0.04, model=model, capturable=use_graph)
     rs = np.random.RandomState(1234 + rank)
@@ -206,7 +212,25 @@ def main():
     y = torch.from_numpy(rs.randint(0, args.classes, args.batch)).to(dev)
     ce = torch.nn.CrossEntropyLoss()
 
+    chunks = []
+    if args.chammi:  # sub-batches of the three chunks (b/3 each, the remainder to the last), their own channel counts
+        sizes = [args.batch // 3, args.batch // 3, args.batch - 2 * (args.batch // 3)]
+        for (name, ids), bsz in zip(chammi_map.items(), sizes):
+            chunks.append((name, torch.from_numpy(rs.standard_normal((bsz, len(ids), args.img, args.img)).astype(np.float32)).to(dev),
+                           torch.from_numpy(rs.randint(0, args.classes, bsz)).to(dev)))
+
+    def chammi_step():
+        opt.zero_grad()
+        for name, xc, yc in chunks:  # trainer.py:846-935: one backward per chunk, gradients accumulate, one optimiser step
+            feat, extra = model(xc, name, None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            loss = dcv.proxy_loss(model.proxies, feat, yc, model.scale) + extra * 1.0
+            loss.backward()
+        opt.step()
+        return loss
+
     def eager_step():
+        if args.chammi:
+            return chammi_step()
         if use_graph:
             opt.advance()
         opt.zero_grad()
@@ -317,7 +341,7 @@ def main():
 
     if rank == 0:
         B, C, H = args.batch, args.channels, {"tiny": 3, "small": 6, "base": 12, "distill": 6}[args.arch]
-        headline = (args.arch, C, args.img, args.batch, args.classes) == ("small", 8, 224, 64, 161) and not args.hcs
+        headline = (args.arch, C, args.img, args.batch, args.classes) == ("small", 8, 224, 64, 161) and not args.hcs and not args.chammi
         n = (args.img // 16) ** 2
         N = C * n + 1
         # ---- roofline of the dominant symbol ----
@@ -375,7 +399,8 @@ def main():
         imgs_med = args.batch * world / (med_ms * 1e-3)
         small8 = (args.arch, C, args.img) == ("small", 8, 224)
         line = {
-            "metric": ("train images/sec, DiChaViT-S 8ch 224^2 bs=64/GPU" if (args.arch, C, args.img, args.batch) == ("small", 8, 224, 64)
+            "metric": ("train images/sec, DiChaViT-S 8ch 224^2 bs=64/GPU" if (args.arch, C, args.img, args.batch) == ("small", 8, 224, 64) and not args.chammi
+                       else f"train images/sec, DiChaViT-{args.arch} CHAMMI 3/4/5ch {args.img}^2 bs={args.batch}/GPU" if args.chammi
                        else f"train images/sec, DiChaViT-{args.arch} {C}ch {args.img}^2 bs={args.batch}/GPU"),
             "value": round(imgs, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -402,7 +427,9 @@ def main():
                            # C_step over the timed steps is the growth of the model's channel histogram (patch_embed.counter)
                            "channels_per_step": round((sum(model.feature_extractor.patch_embed.counter.values()) - picks0) / args.steps, 2),
                            "tokens_per_sec": round(args.batch * world * (args.steps + n * (sum(model.feature_extractor.patch_embed.counter.values()) - picks0)) / dt, 1)}
-                          if args.hcs else {})},
+                          if args.hcs else {}),
+                       **({"chammi": "12-channel model, sub-batches Allen 3ch / HPA 4ch / CP 5ch (N = 589 / 785 / 981 tokens), proxy main loss, "
+                                     "3 forward/backward passes + 1 optimiser step per step; img/s counts the images of all three"} if args.chammi else {})},
             "roofline": roof,
             "kernel_table_mode": "per-launch durations from the profiled warm-up steps, run on one stream (exclusive); "
                                  "ms_per_step and share_of_step refer to that one-stream step",
