@@ -1025,7 +1025,16 @@ extern "C" int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile) {
     const bool legal384 = (N % N3_BN) == 0 && epilogue != DCV_EPI_PATCH;
     if (tile == DCV_TILE_WIDE) return legal384 ? DCV_TILE_WIDE : DCV_ERR_UNSUPPORTED;
     if (tile == DCV_TILE_NARROW) return DCV_TILE_NARROW;
-    return (legal384 && M >= 4096 && (N >= 1152 || K >= 1536) && epilogue != DCV_EPI_GELU_BWD_BF16) ? DCV_TILE_WIDE : DCV_TILE_NARROW;
+    if (!legal384 || epilogue == DCV_EPI_GELU_BWD_BF16 || !(N >= 1152 || K >= 1536)) return DCV_TILE_NARROW;
+    // Both kernels are persistent, so a launch costs rounds x time per tile, rounds = ceil(tiles / workgroups).  A 256 x 384 tile takes
+    // 2.3 (K >= 1536: the k-loop dominates) to 2.5 (K = 384: the epilogue dominates) times a 256 x 128 tile (measured from the per-round
+    // times at M = 12 369 ... 100 416, tools/gemm_mid_m.py, tools/gemm_bench.py): wide wins when its rounds x that factor stay below
+    // the narrow kernel's rounds — always at the headline's M, seldom at a few rounds (M = 25 104, N = 1152: 297 wide tiles = 2 rounds
+    // = 40 us against 891 narrow tiles = 4 rounds = 34 us).
+    const int G = dcv_cu_count();
+    const long tw = (long)((M + N3_BM - 1) / N3_BM) * (N / N3_BN), tn = 3 * tw;
+    const long rw = (tw + G - 1) / G, rn = (tn + G - 1) / G;
+    return (10 * rw * (K >= 1536 ? 23 : 25) < 100 * rn) ? DCV_TILE_WIDE : DCV_TILE_NARROW;
 }
 
 extern "C" int dcv_gemm_tn_pick(int M, int P, int Q, int tile) {

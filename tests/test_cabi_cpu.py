@@ -77,6 +77,14 @@ def test_gemm_tile_choice_rules():
     assert nt(M, 384, 256, hip.EPI_PATCH) == N_                # the tokeniser epilogue lives on the narrow kernel only
     assert nt(M, 200, 384, hip.EPI_PLAIN_BF16, W) < 0 and nt(M, 384, 256, hip.EPI_PATCH, W) < 0 and nt(M, 384, 384, 0, 7) < 0
     assert nt(M, 1152, 384, hip.EPI_BIAS_BF16, N_) == N_ and nt(M, 384, 384, hip.EPI_PLAIN_BF16, W) == W
+    # a few rounds of tiles: rounds x time per tile decides (256 CUs assumed when no device is present, as on the MI355X).
+    # Measured on MI355X (tools/gemm_mid_m.py): M = 12 369 qkv 19.5 us narrow / 20.6 wide, fc1 37.7 / 32.1; M = 16 485 qkv 26.6 / 22.0,
+    # fc1 43.8 / 52.3; M = 25 104 qkv 33.8 / 40.0, fc1T 45.3 / 48.0; M = 50 208 qkv 55.5 / 62.5, fc1T 69.7 / 53.1
+    if lib.dcv_gemm_nt_pick(12369, 1536, 384, hip.EPI_BIAS_GELU_BF16, A) in (N_, W):
+        assert nt(12369, 1152, 384, hip.EPI_BIAS_BF16) == N_ and nt(12369, 1536, 384, hip.EPI_BIAS_GELU_BF16) == W
+        assert nt(16485, 1152, 384, hip.EPI_BIAS_BF16) == W and nt(16485, 1536, 384, hip.EPI_BIAS_GELU_BF16) == N_
+        assert nt(25104, 1152, 384, hip.EPI_BIAS_BF16) == N_ and nt(25104, 384, 1536, hip.EPI_PLAIN_BF16) == N_
+        assert nt(50208, 1152, 384, hip.EPI_BIAS_BF16) == N_ and nt(50208, 384, 1536, hip.EPI_PLAIN_BF16) == W
     tn = lambda p, q, t=A: lib.dcv_gemm_tn_pick(M, p, q, t)
     assert tn(384, 1536) == W and tn(1536, 384) == W and tn(1152, 384) == W
     assert tn(384, 384) == N_ and tn(384, 256) == N_ and tn(200, 128) == N_
