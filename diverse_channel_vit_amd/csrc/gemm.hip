@@ -17,7 +17,7 @@
 
 namespace {
 
-constexpr int BK = 64;  // gemm_tn K-tile (gemm_nt streams NT_BK = 32 stages)
+constexpr int BK = 64;  // gemm_tn_kernel reduction rows per stage (the NT kernels stream NT_BK = N3_BK = 64-wide stages, gemm_tn384 T3_BK = 32 rows)
 
 struct GemmNtArgs {
     const bf16_t* A;
