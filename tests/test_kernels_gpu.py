@@ -112,6 +112,23 @@ def test_gemm_nt_forced_small_grids(hip, M, N, K, tile, grid_cap):
     _check_gemm_nt(hip, M, N, K, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE, grid_cap=grid_cap)
 
 
+def test_gemm_nt_random_shapes_tiles_and_grids(hip):
+    """Seeded random problems through both kernels: M anywhere (partial M tiles, fewer tiles than workgroups, several rounds under a
+    random grid cap), N any multiple of 8 (partial N tiles on the narrow kernel; multiples of 384 also on the wide one), K any multiple
+    of 64 from one to 24 stages — every epilogue each time (_check_gemm_nt)."""
+    rng = np.random.RandomState(20240607)
+    for _ in range(10):
+        M = int(rng.choice([rng.randint(1, 300), rng.randint(300, 3000), rng.randint(3000, 9000)]))
+        K = 64 * int(rng.randint(1, 25))
+        wide = bool(rng.randint(0, 2))
+        N = 384 * int(rng.randint(1, 5)) if wide else 8 * int(rng.randint(1, 193))
+        cap = int(rng.choice([0, 0, 1, 3, 7, 30, 200]))
+        try:
+            _check_gemm_nt(hip, M, N, K, tile=hip.TILE_WIDE if wide else hip.TILE_NARROW, grid_cap=cap)
+        except AssertionError as e:
+            raise AssertionError(f"M={M} N={N} K={K} wide={wide} grid_cap={cap}: {e}") from e
+
+
 def test_gemm_nt_auto_tile_rules(hip):
     """AUTO picks the kernel by shape; an illegal forced variant is refused, not silently replaced."""
     A, W = _bf(512, 384, seed=1), _bf(200, 384, seed=2)
@@ -154,6 +171,21 @@ def _check_gemm_tn(hip, M, P, Q, **kw):
 @pytest.mark.parametrize("M,P,Q", [(1000, 384, 384), (4100, 1152, 384), (333, 384, 1536), (64, 128, 128), (5000, 192, 64), (700, 384, 256)])
 def test_gemm_tn(hip, M, P, Q):
     _check_gemm_tn(hip, M, P, Q)
+
+
+def test_gemm_tn_random_shapes(hip):
+    """Seeded random weight-gradient problems on both kernels: any reduction length (one row .. several thousand: ragged last stage,
+    fewer stages than splits), P / Q multiples of 8 on the 128 x 128 kernel (partial tiles), multiples of 384 / 128 on the wide one."""
+    rng = np.random.RandomState(7)
+    for _ in range(10):
+        M = int(rng.choice([rng.randint(1, 100), rng.randint(100, 2000), rng.randint(2000, 20000)]))
+        wide = bool(rng.randint(0, 2))
+        P = 384 * int(rng.randint(1, 4)) if wide else 8 * int(rng.randint(1, 97))
+        Q = 128 * int(rng.randint(1, 7)) if wide else 8 * int(rng.randint(1, 97))
+        try:
+            _check_gemm_tn(hip, M, P, Q, tile=hip.TILE_WIDE if wide else hip.TILE_NARROW)
+        except AssertionError as e:
+            raise AssertionError(f"M={M} P={P} Q={Q} wide={wide}: {e}") from e
 
 
 @pytest.mark.parametrize("tile", ["narrow", "wide"])
