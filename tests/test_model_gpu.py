@@ -842,7 +842,7 @@ def test_graph_replays_without_host_sync_follow_eager(gpu_device):
     assert diff.max().item() <= 1.5e-3 and diff.mean().item() <= 2e-5, (diff.max().item(), diff.mean().item())
 
 
-def _two_rank_worker(rank, world, port, q, golden_dir):
+def _two_rank_worker(rank, world, port, q, grad_dtype, overlap):
     import os
     import sys
     import torch.distributed as dist
@@ -856,7 +856,7 @@ def _two_rank_worker(rank, world, port, q, golden_dir):
         batches = {(r, k): orc.make_batch(500 + 10 * r + k, 2, 3, 32, 5) for r in range(world) for k in range(2)}
         model, _ = build(meta, dev)
         model.stochastic_weight_rounding = False
-        dp = dcv.DataParallel(model, min_bucket_bytes=1 << 18)
+        dp = dcv.DataParallel(model, min_bucket_bytes=1 << 18, grad_dtype=getattr(torch, grad_dtype), overlap=overlap)
         dp.broadcast_parameters(0)
         dp.hook_misc_params()  # before the first forward (INTEGRATION.md order)
         for k in range(2):  # two backward passes per step
@@ -889,7 +889,8 @@ def _two_rank_worker(rank, world, port, q, golden_dir):
 
 
 @pytest.mark.timeout(600)
-def test_dp_two_ranks_real_model_two_backwards(gpu_device):
+@pytest.mark.parametrize("grad_dtype,overlap", [("float32", True), ("bfloat16", True), ("float32", False)])
+def test_dp_two_ranks_real_model_two_backwards(gpu_device, grad_dtype, overlap):
     """The REAL model + HIP kernels under DataParallel on TWO ranks (both on this box's one GPU; gloo, because RCCL refuses two
     ranks on one device — dp stages gloo reductions through the host), two backward passes per optimiser step, INTEGRATION.md's
     call order, no explicit finalize: gradients must equal the single-process sum over both ranks' batches / world size."""
@@ -898,7 +899,7 @@ def test_dp_two_ranks_real_model_two_backwards(gpu_device):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, None)) for r in range(2)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, grad_dtype, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     import queue as _q
@@ -917,10 +918,12 @@ def test_dp_two_ranks_real_model_two_backwards(gpu_device):
     for p in procs:
         p.join(60)
     for rank, worst, nb, nh in res:
-        assert nb >= 2 and nh <= 8
+        assert nb >= (2 if overlap else 1) and nh <= 8
         if rank == 0:
             print(f"two ranks, two backward passes: worst relative gradient difference vs single-process sum {worst:.2e}")
-            assert worst <= 2e-3  # fp32 atomic ordering noise of the weight-gradient GEMMs only
+            # fp32 exchange: the atomic ordering noise of the weight-gradient GEMMs only; bf16 exchange: every bucket element rounded to bf16
+            # once per pass (2^-9 relative per element)
+            assert worst <= (2e-3 if grad_dtype == "float32" else 8e-3), worst
 
 
 def test_weight_gradients_on_second_stream_match_one_stream(gpu_device):
