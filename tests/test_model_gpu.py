@@ -330,10 +330,16 @@ def test_graphed_step_matches_eager(gpu_device, rounding):
     for a, b in zip(le[2:], lg):
         assert abs(a - b) <= 2e-3, (le, lg)
     we, wg = runs["eager"][1], runs["graph"][1]
-    # nearest: only fp32-atomic ordering separates the two runs.  stochastic: both draw the same bits (the seed word is
-    # bumped on the device, also by replays: 1 + 6 forwards), but ordering noise can flip single roundings, and a flipped
-    # rounding moves Adam's sign-like early steps by up to 2 lr
-    assert (we - wg).abs().max().item() <= (2e-4 if rounding == "nearest" else 1e-3), (we - wg).abs().max().item()
+    # nearest: only the order of the fp32 atomic adds of the weight-gradient GEMMs separates the two runs.  Adam's early steps are
+    # sign-like (|m / sqrt(v)| ~ 1): an element whose true gradient is ~0 can come out with either sign, and each step in which the
+    # two runs disagree moves them apart by up to 2 lr — at most sum_s 2 lr_s = 2 (4 x 1e-4 + 2 x 5e-5) = 1e-3 on single elements
+    # (measured maxima: 1.2e-4 .. 2.3e-4, i.e. one or two such steps), while the MEAN over the 590 k elements stays at the noise
+    # level.  What the test guards — a replay that read a wrong step count / lr — would move EVERY element by ~lr (mean >= 5e-5).
+    # stochastic: both draw the same bits (the seed word is bumped on the device, also by replays: 1 + 6 forwards), but ordering
+    # noise can flip single roundings too.
+    d = (we - wg).abs()
+    print(f"graph vs eager ({rounding}): max |dW| {d.max().item():.2e}, mean {d.mean().item():.2e}")
+    assert d.max().item() <= 1e-3 and d.mean().item() <= (5e-6 if rounding == "nearest" else 2e-5), (d.max().item(), d.mean().item())
     assert runs["eager"][3] == runs["graph"][3] == (None if rounding == "nearest" else 7)
     assert lg[-1] < lg[0]
 
