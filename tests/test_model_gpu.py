@@ -261,14 +261,16 @@ def test_loss_curve_100_steps(gpu_device):
     contribute: they are stochastically rounded every step (include/dcv.h dcv_cast_bf16_sr).  With round-to-nearest
     copies (second run below) Adam's +-lr = 4.9e-5 sign steps are lost below the bf16 ulp, the copies lag the fp32
     master coherently, and the curve is 10x further off (max 6e-2, mean 6e-3) — kept as a regression contrast.
-    Asserted (stochastic, default) at <= 1.5 x the worst of the values measured on MI355X over builds whose kernels differ in
-    the last bit (step0 1.3e-5 .. 9.4e-4, max 5.8e-3 .. 9.1e-3, mean 5.2e-4 .. 5.9e-4, tail 6.7e-5 .. 7.1e-5), so that a
-    regression shows: step0 <= 1.5e-3, max <= 1.4e-2, mean <= 9e-4, last 20 steps <= 2e-4."""
+    Asserted (stochastic, default) at <= 1.5 x the worst of the values measured on MI355X, so that a regression shows.  The
+    trajectory is not reproducible run to run (the fp32 atomic adds of the weight-gradient GEMMs land in a different order every
+    launch, and the early curve amplifies that): 11 runs of the final round-2 build gave step0 8.6e-5, max 5.0e-3 .. 1.07e-2,
+    mean 4.1e-4 .. 7.2e-4, tail 5.7e-5 .. 9.4e-5 (earlier builds: step0 up to 9.4e-4).  Bounds: step0 <= 1.5e-3, max <= 1.6e-2,
+    mean <= 1.1e-3, last 20 steps <= 2e-4."""
     e_sr, ref = _run_curve(gpu_device, "curve100_so2sat_s", True)
     e_rn, _ = _run_curve(gpu_device, "curve100_so2sat_s", False)
     _curve_report("loss-curve so2sat-s stochastic", e_sr, ref)
     _curve_report("loss-curve so2sat-s nearest   ", e_rn, ref)
-    assert e_sr[0] <= 1.5e-3 and e_sr.max() <= 1.4e-2 and e_sr.mean() <= 9e-4 and e_sr[-20:].max() <= 2e-4
+    assert e_sr[0] <= 1.5e-3 and e_sr.max() <= 1.6e-2 and e_sr.mean() <= 1.1e-3 and e_sr[-20:].max() <= 2e-4
     assert e_rn[0] <= 1e-3 and e_rn.max() <= 8.5e-2 and e_rn.mean() <= 8.5e-3 and e_rn[-20:].max() <= 1e-3
     assert e_sr.mean() < 0.5 * e_rn.mean()
 
@@ -279,13 +281,15 @@ def test_loss_curve_headline_architecture(gpu_device):
     steps move by up to 0.3), so the trajectory is sensitive: two builds whose kernels differ in the last bf16 bit measured
     stochastic max 2.8e-2 / mean 1.8e-3 / tail 9e-4 and max 6.6e-2 / mean 4.1e-3 / tail 2.2e-3; round-to-nearest copies
     max 1.2e-1..1.5e-1 / mean 1.0e-2..1.4e-2 / tail 5e-3..7e-3 on the same builds.
-    Asserted (stochastic, default) at 1.5 x the WORSE of the two measured builds: step0 <= 2.1e-3, max <= 0.1, mean <= 6.2e-3,
-    tail <= 3.3e-3; round-to-nearest (contrast only): max <= 0.23, mean <= 2.1e-2."""
+    Run to run on ONE build the spread is as wide (atomic-add order, see above): 11 runs of the final round-2 build gave max
+    1.6e-2 .. 6.0e-2, mean 1.5e-3 .. 3.8e-3, tail 7.7e-4 .. 2.6e-3.
+    Asserted (stochastic, default) at 1.5 x the worst value seen: step0 <= 2.1e-3, max <= 0.1, mean <= 6.2e-3, tail <= 3.9e-3;
+    round-to-nearest (contrast only): max <= 0.23, mean <= 2.1e-2."""
     e_sr, ref = _run_curve(gpu_device, "curve100_jumpcp_s", True)
     e_rn, _ = _run_curve(gpu_device, "curve100_jumpcp_s", False)
     _curve_report("loss-curve headline stochastic", e_sr, ref)
     _curve_report("loss-curve headline nearest   ", e_rn, ref)
-    assert e_sr[0] <= 2.1e-3 and e_sr.max() <= 0.1 and e_sr.mean() <= 6.2e-3 and e_sr[-20:].max() <= 3.3e-3
+    assert e_sr[0] <= 2.1e-3 and e_sr.max() <= 0.1 and e_sr.mean() <= 6.2e-3 and e_sr[-20:].max() <= 3.9e-3
     assert e_rn.max() <= 0.23 and e_rn.mean() <= 2.1e-2
 
 
