@@ -12,6 +12,7 @@
 // gemm_nt: persistent 256x128 (8 waves, 3-stage LDS-DMA ring) and 256x384 (two 80 KB stages) kernels, geometry below.
 // gemm_tn: 128x128 register-staged kernel (4 waves) and the 384x128 LDS-DMA ring kernel (8 waves).
 #include <atomic>
+#include <type_traits>
 #include "dcv_common.hpp"
 #include "../../include/dcv.h"
 
@@ -212,6 +213,157 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
     }
 }
 
+// ---- register epilogue (round 3) -------------------------------------------------------------------------------------------
+// The MFMAs are issued with the operands SWAPPED (W fragment as the A operand, activation fragment as B), so a wave's 16 x 16
+// accumulator tile (i, j) holds, in lane (r16 = lane & 15, kg = lane >> 4), output row m = 16 i + r16 and the FOUR CONSECUTIVE
+// columns n = 16 j + 4 kg .. +3 — row-contiguous data in every lane, which two register shuffles turn into full cache lines:
+//   1. bf16 outputs only: four v_permlane16_swap per tile pair (j, j + 1) leave lane (r16, kg) with the EIGHT consecutive columns
+//      16 (j + (kg & 1)) + 8 (kg >> 1) .. +7 of its row (the swap exchanges the odd 16-lane rows of its first operand with the even
+//      rows of its second): 16 bytes per lane, but still only 4 lanes = 64 bytes per output row and instruction;
+//   2. a DPP exchange between lanes l and l ^ 8 (row_ror:8, two v_mov_dpp per register) between two such column halves: afterwards
+//      one store instruction covers rows rr = r16 & 7 (+ 8 for the second instruction) with EIGHT lanes per row — 8 rows x 128
+//      contiguous bytes, whole cache lines, exactly what the LDS slab of rounds 1-2 produced.  (Measured without step 2: 16 half-lines
+//      per instruction instead of 8 lines made every epilogue 5-25 % SLOWER than the slab — the store path is bound by the number of
+//      lines an instruction touches, not by bytes; gpurun r3b.)
+// Final layout of a lane inside a column group: bf16: 64-column group, 8 columns at 32 (r16 >> 3) + 16 (kg & 1) + 8 (kg >> 1);
+// fp32: 32-column group (a tile pair), 4 columns at 16 (r16 >> 3) + 4 kg; rows rr and rr + 8 of the 16-row block.
+// No LDS: the whole ring is free for the next tile's prefetch and no workgroup barrier separates the k-loop from the epilogue.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap_pair8(const f32x4& t0, const f32x4& t1, float* v) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const u32x2_t u = __builtin_amdgcn_permlane16_swap(__float_as_uint(t0[r]), __float_as_uint(t1[r]), false, false);
+        v[r] = __uint_as_float(u[0]);
+        v[4 + r] = __uint_as_float(u[1]);
+    }
+}
+// x (lower column half) / y (upper column half), both held for row r16: afterwards a = (row rr: x of lanes r16 < 8 | y of lane l - 8),
+// b = (row rr + 8: x of lane l + 8 | y of lanes r16 >= 8)
+__device__ __forceinline__ void xchg_rows8(float x, float y, float& a, float& b) {
+    const int xi = __float_as_int(x), yi = __float_as_int(y);
+    a = __int_as_float(__builtin_amdgcn_update_dpp(xi, yi, 0x128, 0xF, 0xC, false));  // lanes 8-15 of every row: y[l ^ 8]
+    b = __int_as_float(__builtin_amdgcn_update_dpp(yi, xi, 0x128, 0xF, 0x3, false));  // lanes 0-7: x[l ^ 8]
+}
+// fp32-output epilogues on 4 consecutive columns n .. n+3 of row m
+template <int EPI>
+__device__ __forceinline__ void epi_aux4(const GemmNtArgs& a, int m, int n, float* x) {
+    if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
+        const float* rsd = a.aux ? (const float*)a.aux + (size_t)m * a.ldaux + n : (const float*)a.out + (size_t)m * a.ldo + n;
+        const float4 v = *reinterpret_cast<const float4*>(rsd);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else if constexpr (EPI == DCV_EPI_PATCH) {
+        const int b = m / a.T, t = m - b * a.T;
+        const int c = t / a.n, i = t - c * a.n;
+        const float4 e = *reinterpret_cast<const float4*>((const float*)a.aux + (size_t)c * a.ldaux + n);
+        const float4 p = *reinterpret_cast<const float4*>(a.aux2 + (size_t)(1 + i) * a.ldaux + n);
+        x[0] = e.x + p.x; x[1] = e.y + p.y; x[2] = e.z + p.z; x[3] = e.w + p.w;
+    }
+}
+template <int EPI>
+__device__ __forceinline__ void epi_store4(const GemmNtArgs& a, int m, int n, const f32x4& acc, const float* x, const float4& bz) {
+    float4 v = make_float4(acc[0] + bz.x, acc[1] + bz.y, acc[2] + bz.z, acc[3] + bz.w);
+    if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
+        v.x += x[0]; v.y += x[1]; v.z += x[2]; v.w += x[3];
+        *reinterpret_cast<float4*>((float*)a.out + (size_t)m * a.ldo + n) = v;
+    } else if constexpr (EPI == DCV_EPI_PATCH) {
+        const int b = m / a.T, t = m - b * a.T;
+        if (a.out2) *reinterpret_cast<float4*>((float*)a.out2 + (size_t)m * a.ldo2 + n) = v;  // pre-embedding tokens (ortho loss input)
+        v.x += x[0]; v.y += x[1]; v.z += x[2]; v.w += x[3];
+        *reinterpret_cast<float4*>((float*)a.out + ((size_t)b * (a.T + 1) + 1 + t) * a.ldo + n) = v;
+    }
+}
+template <int EPI>
+__device__ constexpr bool epi_f32out() { return EPI == DCV_EPI_BIAS_RESID_F32 || EPI == DCV_EPI_PATCH; }
+
+// Epilogue of a wave's 64-row x (16 NJ)-column block of accumulators acc[4][J0 .. J0 + NJ) (NJ a multiple of 4), rows m_w + 16 i + ..,
+// columns n_w + ..; `between()` runs after the first auxiliary loads have been issued and before anything is stored (the persistent
+// kernels put the next tile's prefetch there).  NI: row blocks (of 16 rows) whose auxiliary loads are issued together (4 = all of
+// them before `between`; fewer = fewer registers).  bz: the lane's bias values in its final layout (nt_load_bias).
+template <int EPI, int NI, int NJ, int NJT, int J0, class Between>
+__device__ __forceinline__ void nt_epilogue_block(const GemmNtArgs& a, const f32x4 (&acc)[4][NJT], int m_w, int n_w, int r16, int kg,
+                                                  const float* bz, Between&& between) {
+    constexpr bool HAS_AUX = (EPI == DCV_EPI_BIAS_RESID_F32) || (EPI == DCV_EPI_GELU_BWD_BF16) || (EPI == DCV_EPI_PATCH);
+    const int rr = r16 & 7, hi = r16 >> 3;
+    if constexpr (epi_f32out<EPI>()) {
+        constexpr int NG = NJ / 2;  // 32-column groups
+        const int cl = 16 * hi + 4 * kg;
+#pragma unroll
+        for (int ib = 0; ib < 4; ib += NI) {
+            float x[NI][NG][2][4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int c = 0; c < NG; ++c)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        epi_aux4<EPI>(a, min(m_w + 16 * (ib + i) + 8 * h + rr, a.M - 1), min(n_w + 32 * c + cl, a.N - 4), x[i][c][h]);
+            if (ib == 0) between();
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    f32x4 va, vb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float fa, fb;
+                        xchg_rows8(acc[ib + i][J0 + 2 * c][r], acc[ib + i][J0 + 2 * c + 1][r], fa, fb);
+                        va[r] = fa; vb[r] = fb;
+                    }
+                    const int m = m_w + 16 * (ib + i) + rr, n = n_w + 32 * c + cl;
+                    const float4 b4 = make_float4(bz[4 * c], bz[4 * c + 1], bz[4 * c + 2], bz[4 * c + 3]);
+                    if (m < a.M && n < a.N) epi_store4<EPI>(a, m, n, va, x[i][c][0], b4);
+                    if (m + 8 < a.M && n < a.N) epi_store4<EPI>(a, m + 8, n, vb, x[i][c][1], b4);
+                }
+        }
+    } else {
+        constexpr int NG = NJ / 4;  // 64-column groups
+        const int cl = 32 * hi + 16 * (kg & 1) + 8 * (kg >> 1);
+#pragma unroll
+        for (int ib = 0; ib < 4; ib += NI) {
+            float x[HAS_AUX ? NI : 1][HAS_AUX ? NG : 1][2][8];
+            if constexpr (HAS_AUX) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int c = 0; c < NG; ++c)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            epi_aux8<EPI>(a, min(m_w + 16 * (ib + i) + 8 * h + rr, a.M - 1), min(n_w + 64 * c + cl, a.N - 8), x[i][c][h]);
+            }
+            if (ib == 0) between();
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    float v0[8], v1[8], va[8], vb[8];
+                    swap_pair8(acc[ib + i][J0 + 4 * c], acc[ib + i][J0 + 4 * c + 1], v0);
+                    swap_pair8(acc[ib + i][J0 + 4 * c + 2], acc[ib + i][J0 + 4 * c + 3], v1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xchg_rows8(v0[e], v1[e], va[e], vb[e]);
+                    const int m = m_w + 16 * (ib + i) + rr, n = n_w + 64 * c + cl;
+                    if (m < a.M && n < a.N) epi_store8<EPI>(a, m, n, va, x[HAS_AUX ? i : 0][HAS_AUX ? c : 0][0], bz + 8 * c);
+                    if (m + 8 < a.M && n < a.N) epi_store8<EPI>(a, m + 8, n, vb, x[HAS_AUX ? i : 0][HAS_AUX ? c : 0][1], bz + 8 * c);
+                }
+        }
+    }
+}
+// the lane's bias values for a block of NJ column tiles starting at column n_w, in its final layout: fp32 outputs NJ / 2 x 4 floats,
+// bf16 outputs NJ / 4 x 8 floats (2 NJ floats either way)
+template <int EPI, int NJ>
+__device__ __forceinline__ void nt_load_bias(const GemmNtArgs& a, int n_w, int r16, int kg, float* bz) {
+    const int hi = r16 >> 3;
+    if constexpr (epi_f32out<EPI>()) {
+#pragma unroll
+        for (int c = 0; c < NJ / 2; ++c) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + min(n_w + 32 * c + 16 * hi + 4 * kg, a.N - 4));
+            bz[4 * c] = b.x; bz[4 * c + 1] = b.y; bz[4 * c + 2] = b.z; bz[4 * c + 3] = b.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NJ / 4; ++c) load8_f32(a.bias + min(n_w + 64 * c + 32 * hi + 16 * (kg & 1) + 8 * (kg >> 1), a.N - 8), bz + 8 * c);
+    }
+}
+
 // gemm_nt geometry: 256 x 128 output tile, 8 waves as 4 (M) x 2 (N), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles
 // (same FLOPs per cycle as 32x32x16, but the power-limited chip clocks higher on it: NT GEMMs 3-9 % faster, profiles/r02_x4_*).
 // Measured on MI355X (tools/ab_bench.py ablations, M = 100 416, K = 384):
@@ -231,6 +383,15 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
 #endif
 #ifndef DCV_GABL
 #define DCV_GABL 0  // timing-only ablations: 1 = no epilogue, 2 = no MFMA/LDS reads, 3 = no operand DMA
+#endif
+#ifndef DCV_AWRAP
+#define DCV_AWRAP 0  // timing-only probe: the A operand's rows wrap to the first DCV_AWRAP rows (A stays L2-resident; outputs are wrong)
+#endif
+#ifndef DCV_N3_EARLY_AT
+#define DCV_N3_EARLY_AT 11  // gemm_nt384_kernel: waves 0-3 issue their DMA pieces behind MFMA step N of the stage (11 = between the two k-steps), waves 4-7 at the top; -1: all at the top.  Stamps (profiles/r03_x1_*): with all eight waves issuing first the matrix pipe idled ~640 cycles per stage (80 pieces x 16 TA cycles, older waves served first); -4 ... -8 % on the k-loop-heavy shapes
+#endif
+#ifndef DCV_STAGGER
+#define DCV_STAGGER 0  // probe: every other workgroup of an XCD starts DCV_STAGGER x 8128 cycles late
 #endif
 #ifndef DCV_READ_FIRST
 #define DCV_READ_FIRST 1  // gemm_nt384_kernel: a stage's first fragment reads are issued BEFORE the next stage's ten DMA pieces (-2 %; the narrow kernel and gemm_tn384 measured slower / equal with it)
@@ -264,7 +425,11 @@ __device__ __forceinline__ void nt_tile_setup(const GemmNtArgs& a, int L, int ti
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = 32 * wave + 8 * q + (lane >> 3);
+#if DCV_AWRAP
+        t.gA[q] = a.A + (size_t)(min(t.m0 + row, a.M - 1) % DCV_AWRAP) * a.lda + (((lane & 7) ^ swz64n(row)) * 8);
+#else
         t.gA[q] = a.A + (size_t)min(t.m0 + row, a.M - 1) * a.lda + (((lane & 7) ^ swz64n(row)) * 8);
+#endif
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -289,7 +454,6 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     // ONE shared array (a second __shared__ object can make hipcc drain vmcnt before every ds_read)
     __shared__ __attribute__((aligned(16))) char smem[NT_SMEM];
     constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
-    constexpr bool HAS_AUX = (EPI == DCV_EPI_BIAS_RESID_F32) || (EPI == DCV_EPI_GELU_BWD_BF16) || (EPI == DCV_EPI_PATCH);
     constexpr int S = nt_stores_per_wave<EPI>();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -308,8 +472,6 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     const int nk = a.K / NT_BK;
     const int r16 = lane & 15, kg = lane >> 4;  // 16x16x32 fragments: row / column r16, k-chunk kg (8 elements)
     const int rowA = (wm * 64 + r16) * 128, rowW = NT_A_BYTES + (wn * 64 + r16) * 128;  // + 16 i rows
-    constexpr int EP_LD = 68;  // floats per slab row (272 B: 16-byte aligned, rows shifted by 4 banks)
-    const int erow = lane >> 3, ecol = (lane & 7) * 8;
 
     // tile order: round k, workgroup w -> k*G + pos(w)
     int L = pos < total ? pos : -1;
@@ -327,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
     // drained the previous tile's stores and the prefetch: fc2 + residual ran 40 % slower than without persistence.)
     float bz[8], bz_next[8];
     if constexpr (HAS_BIAS) {
-        load8_f32(a.bias + min(cur.n0 + wn * 64 + ecol, a.N - 8), bz);
+        nt_load_bias<EPI, 4>(a, cur.n0 + wn * 64, r16, kg, bz);
 #pragma unroll
         for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(bz[e]));
     }
@@ -388,63 +550,45 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], wf[j], acc[i][j]);
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);  // operands swapped: the tile comes out transposed (register epilogue)
             }
 #else
             asm volatile("" ::"v"(st));
 #endif
         }
-        __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: its buffer (g-1)%3 now holds the slabs
+        // no barrier here: the epilogue reads no LDS, and the two ring buffers the prefetch below fills (stages g-3 and g-2 of this
+        // workgroup's stream) were last read before barriers every wave has already passed
 #if DCV_STAMP
         const unsigned long long st_t1 = clock64();
         st_loop += st_t1 - st_t0;
 #endif
 
-        // ---- epilogue of `cur`, overlapped with the first two stages of the next tile ----
+        // ---- epilogue of `cur` straight from the accumulators, overlapped with the first two stages of the next tile ----
         const int Ln = Lnext;
         const bool has_next = Ln >= 0;
         Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
-        const int mbase = cur.m0 + wm * 64, nn = cur.n0 + wn * 64 + ecol;
-        const int nc = min(nn, a.N - 8);
-        float x[HAS_AUX ? 8 : 1][8];
-        if constexpr (HAS_AUX) {  // all auxiliary loads first: they are then OLDER than the prefetch DMAs below, so
-                                  // hipcc's own waits for them never wait for the prefetch
-#pragma unroll
-            for (int qq = 0; qq < 8; ++qq) epi_aux8<EPI>(a, min(mbase + qq * 8 + erow, a.M - 1), nc, x[qq]);
-        }
-        if (has_next) {
-            nt_tile_setup(a, Ln, tiles_n, wave, lane, nxt);
-            if constexpr (HAS_BIAS) load8_f32(a.bias + min(nxt.n0 + wn * 64 + ecol, a.N - 8), bz_next);
-            nt_issue(nxt, 0, smem_base + (g % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
-            if (nk > 1) nt_issue(nxt, 1, smem_base + ((g + 1) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
-        }
+        const bool full = (cur.m0 + NT_BM <= a.M) && (cur.n0 + NT_BN <= a.N) && (EPI != DCV_EPI_PATCH);
 #if DCV_GABL == 1
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-        const bool full = false;
-#else
-        // wave-private slab (16 rows x 64 cols f32) in the buffer consumed last; LDS operations of one wave execute in
-        // order, so the write -> read -> next write sequence needs no barrier
-        float* ep = reinterpret_cast<float*>(smem + ((g + NT_STAGES - 1) % NT_STAGES) * NT_STAGE_BYTES) + wave * 16 * EP_LD;
-        const bool full = (cur.m0 + NT_BM <= a.M) && (cur.n0 + NT_BN <= a.N) && (EPI != DCV_EPI_PATCH);
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {  // quarter = the 16 rows of MFMA row block qt: lane (r16, kg) holds rows 4 kg .. +3 of column 16 j + r16
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ep[(4 * kg + r) * EP_LD + j * 16 + r16] = acc[qt][j][r];
-#pragma unroll
-            for (int ps = 0; ps < 2; ++ps) {  // 16 rows x 8 chunks = 128 items = 2 passes
-                const int row = ps * 8 + erow;
-                const int qq = qt * 2 + ps;
-                const int mm = mbase + qq * 8 + erow;
-                float v[8];
-                load8_f32(ep + row * EP_LD + ecol, v);
-                if (mm < a.M && nn < a.N) epi_store8<EPI>(a, mm, nn, v, x[HAS_AUX ? qq : 0], bz);
-            }
+        if (has_next) {
+            nt_tile_setup(a, Ln, tiles_n, wave, lane, nxt);
+            nt_issue(nxt, 0, smem_base + (g % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+            if (nk > 1) nt_issue(nxt, 1, smem_base + ((g + 1) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
         }
+#else
+        // all auxiliary loads first (they are then OLDER than the prefetch DMAs, so hipcc's own waits for them never wait for the
+        // prefetch), then the next tile's bias and first two stages, then the fused op and the stores
+        nt_epilogue_block<EPI, (EPI == DCV_EPI_PATCH ? 1 : 4), 4, 4, 0>(a, acc, cur.m0 + wm * 64, cur.n0 + wn * 64, r16, kg, bz, [&]() {
+            if (has_next) {
+                nt_tile_setup(a, Ln, tiles_n, wave, lane, nxt);
+                if constexpr (HAS_BIAS) nt_load_bias<EPI, 4>(a, nxt.n0 + wn * 64, r16, kg, bz_next);
+                nt_issue(nxt, 0, smem_base + (g % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+                if (nk > 1) nt_issue(nxt, 1, smem_base + ((g + 1) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+            }
+        });
 #endif
 #if DCV_STAMP
         st_t0 = clock64();
@@ -476,6 +620,16 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
 // (8 waves as 4 (M) x 2 (N), each 64 x 192 = 4 x 12 MFMA 16x16x32 tiles; the k-step's read / MFMA order is pinned, see the loop) and the
 // whole LDS: two 80 KB stages.  With two buffers the next stage is issued after the barrier that retires the previous
 // one, one k-iteration (48 MFMAs per wave) ahead.  Tile walk, slab epilogue and fused ops as in gemm_nt_kernel.
+#if DCV_STAMP == 2
+// fine stamps (diagnostic build only): one statement = s_memtime + its wait, fenced for the scheduler (cdna guide, In-kernel stamps)
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
 constexpr int N3_BM = 256, N3_BN = 384, N3_BK = 64;
 constexpr int N3_A_BYTES = N3_BM * N3_BK * 2, N3_W_BYTES = N3_BN * N3_BK * 2, N3_STAGE_BYTES = N3_A_BYTES + N3_W_BYTES;  // 80 KB
 constexpr int N3_SMEM = 2 * N3_STAGE_BYTES;                                                                              // 160 KB
@@ -485,14 +639,18 @@ template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[N3_SMEM];
     constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
-    constexpr bool HAS_AUX = (EPI == DCV_EPI_BIAS_RESID_F32) || (EPI == DCV_EPI_GELU_BWD_BF16);
     static_assert(EPI != DCV_EPI_PATCH, "the tokeniser epilogue stays on the 256 x 128 kernel");
     constexpr int S = 3 * nt_stores_per_wave<EPI>();  // stores one wave issues in a full tile's epilogue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const bool late = (wave >> 2) != 0;  // waves w and w + 4 share a SIMD
     const int tiles_n = a.N / N3_BN;
     const int tiles_m = (a.M + N3_BM - 1) / N3_BM;
+#if DCV_STAGGER
+    if ((blockIdx.x >> 3) & 1)
+        for (int i = 0; i < DCV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const int total = tiles_m * tiles_n;
     const int G = gridDim.x;
     const int pos = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
@@ -502,8 +660,12 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     const int nk = a.K / N3_BK;
     const int r16 = lane & 15, kg = lane >> 4;  // 16x16x32 fragments: row / column r16, k-chunk kg (8 elements)
     const int rowA = (wm * 64 + r16) * 128, rowW = N3_A_BYTES + (wn * 192 + r16) * 128;  // + 16 i / 16 j rows
-    constexpr int EP_LD = 68;
-    const int erow = lane >> 3, ecol = (lane & 7) * 8;
+    int fA0, fA1, fW0, fW1;  // per-lane fragment read offsets inside a stage: operand x k-step
+    {
+        const int co0 = (kg ^ swz64n(r16)) << 4;
+        fA0 = rowA + co0; fA1 = rowA + (co0 ^ 64); fW0 = rowW + co0; fW1 = rowW + (co0 ^ 64);
+        asm volatile("" : "+v"(fA0), "+v"(fA1), "+v"(fW0), "+v"(fW1));
+    }
 
     // DMA sources: a scalar tile base + per-lane byte offsets that do not depend on the tile (the partial last M tile
     // recomputes the A offsets with its rows clamped to M-1)
@@ -520,7 +682,11 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     }
     auto issue = [&](int m0_, int n0_, int kt, unsigned stage_base) {
         const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);  // uniform by construction
+#if DCV_AWRAP
+        const bf16_t* ab = a.A + (size_t)(m0 % DCV_AWRAP) * a.lda + kt * N3_BK;
+#else
         const bf16_t* ab = a.A + (size_t)m0 * a.lda + kt * N3_BK;  // scalar
+#endif
         const bf16_t* wb = a.W + (size_t)n0 * a.ldw + kt * N3_BK;
         if (m0 + N3_BM <= a.M) {
 #pragma unroll
@@ -553,6 +719,9 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
 #if DCV_STAMP  // diagnostic build only (tools/gemm_stamp.py): per-workgroup cycles in the k-loop vs the epilogue, written through aux2
     unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = clock64();
 #endif
+#if DCV_STAMP == 2
+    unsigned long long fs_vm = 0, fs_bar = 0, fs_issue = 0, fs_mfma = 0;
+#endif
     for (;;) {
         f32x4 acc[4][12];  // wave tile 64 x 192 = 4 x 12 MFMA tiles of 16 x 16
 #pragma unroll
@@ -566,9 +735,18 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         for (int kt = 0; kt < nk; ++kt, ++g) {
             // stage kt landed once only younger operations are outstanding: for kt == 0 the previous tile's S epilogue
             // stores (issued after this tile's first stage); afterwards nothing of ours is younger than the stage
+#if DCV_STAMP == 2
+            const unsigned long long f0 = stamp_now();
+#endif
             if (kt == 0 && stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if DCV_STAMP == 2
+            const unsigned long long f0b = stamp_now();
+#endif
             __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done with buffer (g+1)&1 (reads / slabs)
+#if DCV_STAMP == 2
+            const unsigned long long f1 = stamp_now();
+#endif
             // (issuing half the waves' pieces between the two k-steps, as gemm_nt_kernel does, measured 3-5 % slower here: with two
             // stages the late pieces have half a stage to land)
 #if !DCV_READ_FIRST
@@ -579,72 +757,78 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             // the 4 A fragments of the second k-step replace those of the first one by one behind their last MFMA.  The order
             // is pinned (sched_barrier): left alone, hipcc hoists all 16 reads of a k-step and spills accumulators (192 of the
             // 256 registers a wave has at 8 waves per workgroup are accumulators).
-            const int co0 = (kg ^ swz64n(r16)) << 4;  // k-step 0: chunk kg; k-step 1: chunk 4 + kg = co0 ^ 64.  swz64n(16 i + r16) is the same for every i
-            auto rdW = [&](int s2) { return as_bf16x8(lds_read128(st, rowW + (s2 % 12) * 16 * 128 + (co0 ^ (s2 >= 12 ? 64 : 0)))); };
+            // k-step 0: chunk kg; k-step 1: chunk 4 + kg = co0 ^ 64.  swz64n(16 i + r16) is the same for every i.  The four per-lane
+            // bases (A / W x k-step) are opaque values, so every fragment read is base + immediate (left to itself hipcc built one
+            // address register per column block for the second k-step — twelve registers it then spilled around the loop)
+            const char* const pA0 = st + fA0;
+            const char* const pA1 = st + fA1;
+            const char* const pW0 = st + fW0;
+            const char* const pW1 = st + fW1;
+            auto rdW = [&](int s2) { return as_bf16x8(lds_read128(s2 >= 12 ? pW1 : pW0, (s2 % 12) * 16 * 128)); };
             bf16x8 af[4], wq[3];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = as_bf16x8(lds_read128(st, rowA + i * 16 * 128 + co0));
+            for (int i = 0; i < 4; ++i) af[i] = as_bf16x8(lds_read128(pA0, i * 16 * 128));
             wq[0] = rdW(0);
             wq[1] = rdW(1);
             __builtin_amdgcn_sched_barrier(0);
 #if DCV_READ_FIRST
-            if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
+            if (kt + 1 < nk && (DCV_N3_EARLY_AT < 0 || late)) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
             __builtin_amdgcn_sched_barrier(0);
+#endif
+#if DCV_STAMP == 2
+            const unsigned long long f2 = stamp_now();
 #endif
 #pragma unroll
             for (int s2 = 0; s2 < 24; ++s2) {
                 if (s2 + 2 < 24) wq[(s2 + 2) % 3] = rdW(s2 + 2);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc[i][s2 % 12] = mfma16(af[i], wq[s2 % 3], acc[i][s2 % 12]);
-                    if (s2 == 11) af[i] = as_bf16x8(lds_read128(st, rowA + i * 16 * 128 + (co0 ^ 64)));
+                    acc[i][s2 % 12] = mfma16(wq[s2 % 3], af[i], acc[i][s2 % 12]);  // operands swapped: transposed tile (register epilogue)
+                    if (s2 == 11) af[i] = as_bf16x8(lds_read128(pA1, i * 16 * 128));
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (DCV_N3_EARLY_AT >= 0 && s2 == DCV_N3_EARLY_AT) {
+                    if (kt + 1 < nk && !late) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+#if DCV_STAMP == 2
+            const unsigned long long f3 = stamp_now();
+            fs_vm += f0b - f0; fs_bar += f1 - f0b; fs_issue += f2 - f1; fs_mfma += f3 - f2;
+#endif
         }
-        __builtin_amdgcn_s_barrier();  // every wave has consumed the last stage: buffer (g-1)&1 now holds the slabs
+        // The next tile's first stage goes into buffer g & 1 = the buffer of stage g-2, which every wave finished reading before the
+        // barrier of iteration g-1: no barrier is needed here (the epilogue reads no LDS).
 #if DCV_STAMP
         const unsigned long long st_t1 = clock64();
         st_loop += st_t1 - st_t0;
 #endif
 
-        // ---- epilogue, overlapped with the first stage of the next tile (into the other buffer) ----
+        // ---- epilogue straight from the accumulators, overlapped with the first stage of the next tile (into the other buffer) ----
         const int Ln = Lnext;
         const bool has_next = Ln >= 0;
         const int m0n = has_next ? (Ln / tiles_n) * N3_BM : 0, n0n = has_next ? (Ln % tiles_n) * N3_BN : 0;
         Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
-        if (has_next) issue(m0n, n0n, 0, smem_base + (g & 1) * N3_STAGE_BYTES);
-        float* ep = reinterpret_cast<float*>(smem + ((g + 1) & 1) * N3_STAGE_BYTES) + wave * 16 * EP_LD;
         const bool full = (m0 + N3_BM <= a.M);
-        const int mbase = m0 + wm * 64;
-#pragma unroll
-        for (int cg = 0; cg < 3; ++cg) {  // 64-column groups of the wave's 192 columns
-            const int nn = n0 + wn * 192 + cg * 64 + ecol;
+        const int m_w = m0 + wm * 64, n_w = n0 + wn * 192;
+        // the lane id goes through an opaque move: otherwise hipcc hoists the epilogue's per-lane row / column offsets above the k-loop,
+        // where 192 accumulators are live, spills them, and reloads DMA offsets from scratch inside the loop (a scratch load is a
+        // vector-memory operation: its wait drains the ring)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int r16e = ln & 15, kge = ln >> 4;
+        // column blocks of 64 x row blocks of 16
+        auto block = [&](auto j0c, auto&& between) {
+            constexpr int J0 = decltype(j0c)::value;
             float bz[8];
-            if constexpr (HAS_BIAS) load8_f32(a.bias + nn, bz);
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {  // quarter = the 16 rows of MFMA row block qt: lane (r16, kg) holds rows 4 kg .. +3
-                constexpr bool AUX_EARLY = HAS_AUX;  // the auxiliary rows of both passes are loaded before the slab round trip
-                float x[AUX_EARLY ? 2 : 1][8];
-                if constexpr (AUX_EARLY) {
-#pragma unroll
-                    for (int ps = 0; ps < 2; ++ps) epi_aux8<EPI>(a, min(mbase + (qt * 2 + ps) * 8 + erow, a.M - 1), nn, x[ps]);
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ep[(4 * kg + r) * EP_LD + j * 16 + r16] = acc[qt][4 * cg + j][r];
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int row = ps * 8 + erow;
-                    const int mm = mbase + (qt * 2 + ps) * 8 + erow;
-                    if constexpr (HAS_AUX && !AUX_EARLY) epi_aux8<EPI>(a, min(mm, a.M - 1), nn, x[0]);
-                    float v[8];
-                    load8_f32(ep + row * EP_LD + ecol, v);
-                    if (mm < a.M) epi_store8<EPI>(a, mm, nn, v, x[AUX_EARLY ? ps : 0], bz);
-                }
-            }
-        }
+            if constexpr (HAS_BIAS) nt_load_bias<EPI, 4>(a, n_w + 16 * J0, r16e, kge, bz);
+            nt_epilogue_block<EPI, 1, 4, 12, J0>(a, acc, m_w, n_w + 16 * J0, r16e, kge, bz, between);
+        };
+        block(std::integral_constant<int, 0>{}, [&]() {
+            if (has_next) issue(m0n, n0n, 0, smem_base + (g & 1) * N3_STAGE_BYTES);
+        });
+        block(std::integral_constant<int, 4>{}, []() {});
+        block(std::integral_constant<int, 8>{}, []() {});
 #if DCV_STAMP
         st_t0 = clock64();
         st_epi += st_t0 - st_t1;
@@ -656,10 +840,15 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         n0 = n0n;
         L = Ln;
     }
-#if DCV_STAMP
+#if DCV_STAMP == 1
     if (tid == 0 && a.aux2) {
         unsigned long long* sp = (unsigned long long*)a.aux2 + 4 * blockIdx.x;
         sp[0] = st_loop; sp[1] = st_epi; sp[2] = st_n; sp[3] = clock64();
+    }
+#elif DCV_STAMP == 2
+    if (lane == 0 && a.aux2) {  // per wave: vmcnt wait, barrier wait, reads + DMA issue, MFMA steps, epilogue, tiles
+        unsigned long long* sp = (unsigned long long*)a.aux2 + 8 * (8 * blockIdx.x + wave);
+        sp[0] = fs_vm; sp[1] = fs_bar; sp[2] = fs_issue; sp[3] = fs_mfma; sp[4] = st_epi; sp[5] = st_n; sp[6] = st_loop; sp[7] = 0;
     }
 #endif
 }
@@ -675,6 +864,8 @@ struct GemmTnArgs {
     int lddw;
     float* dbias;
     int m_per_split, splits;
+    float* part;       // deterministic mode: split s stores its partial tile to part[s * part_stride + p * Q + q] (and its bias partial to
+    long part_stride;  // part[s * part_stride + P * Q + p]) with plain stores instead of adding atomically; det_reduce_kernel sums them
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
@@ -792,7 +983,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = p0 + wm * 64 + i * 32 + acc_row(r, h);
-                if (p < a.P) atomicAdd(a.dW + (size_t)p * a.lddw + q, acc[i][j][r]);
+                if (p < a.P) {
+                    if (a.part) a.part[(size_t)split * a.part_stride + (size_t)p * a.Q + q] = acc[i][j][r];
+                    else atomicAdd(a.dW + (size_t)p * a.lddw + q, acc[i][j][r]);
+                }
             }
         }
 
@@ -808,7 +1002,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) s += red[(rr * 16 + ch) * 8 + e];
             int p = p0 + ch * 8 + e;
-            if (p < a.P) atomicAdd(a.dbias + p, s);
+            if (p < a.P) {
+                if (a.part) a.part[(size_t)split * a.part_stride + (size_t)a.P * a.Q + p] = s;
+                else atomicAdd(a.dbias + p, s);
+            }
         }
     }
 }
@@ -962,7 +1159,8 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = p0 + wp * 96 + i * 32 + acc_row(r, h);
-                atomicAdd(a.dW + (size_t)p * a.lddw + q, acc[i][j][r]);
+                if (a.part) a.part[(size_t)split * a.part_stride + (size_t)p * a.Q + q] = acc[i][j][r];
+                else atomicAdd(a.dW + (size_t)p * a.lddw + q, acc[i][j][r]);
             }
         }
     if (do_bias) {
@@ -977,8 +1175,29 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
             float sum = 0.f;
 #pragma unroll
             for (int g = 0; g < 10; ++g) sum += red[g * 384 + tid];
-            atomicAdd(a.dbias + p0 + tid, sum);
+            if (a.part) a.part[(size_t)split * a.part_stride + (size_t)a.P * a.Q + p0 + tid] = sum;
+            else atomicAdd(a.dbias + p0 + tid, sum);
         }
+    }
+}
+
+// Deterministic mode, second pass: dst[c] += part[0][c] + part[1][c] + ... in THAT order (a fixed summation order whatever the dispatch
+// order was), four columns per thread.  Columns [0, P*Q) are the weight gradient (row stride lddw), [P*Q, P*Q + P) the bias gradient.
+__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int nparts, long part_stride, float* __restrict__ dW,
+                                                         int lddw, float* __restrict__ dbias, int P, int Q) {
+    const long pq = (long)P * Q, n4 = (pq + (dbias ? P : 0)) >> 2;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n4; v += (long)gridDim.x * 256) {
+        const long c = v << 2;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = part + c;
+        for (int k = 0; k < nparts; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(src + (size_t)k * part_stride);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float* d = (c < pq) ? dW + (c / Q) * (long)lddw + (c % Q) : dbias + (c - pq);
+        float4 o = *reinterpret_cast<float4*>(d);
+        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+        *reinterpret_cast<float4*>(d) = o;
     }
 }
 
@@ -1095,8 +1314,30 @@ extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M
     return dcv_gemm_nt_ex(A, lda, W, ldw, M, N, K, epilogue, bias, out, ldo, out2, ldo2, aux, ldaux, aux2, T, n, 0, DCV_TILE_AUTO, stream);
 }
 
-extern "C" int dcv_gemm_tn_acc_ex(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,
-                                  float* dbias, int tile, void* stream) {
+// splits / rows per split of a weight-gradient launch (pure function of the problem, the tile and the device's CU count)
+static void tn_plan(int M, int P, int Q, int pick, int cus, int& splits, int& mps) {
+    if (pick == DCV_TILE_WIDE) {
+        const int tiles3 = (P / 384) * (Q / 128);
+        splits = cus / tiles3;  // one 128 KB workgroup per CU, one resident round
+        const int max3 = (M + T3_BK - 1) / T3_BK;
+        if (splits > max3) splits = max3;
+        if (splits < 1) splits = 1;
+        mps = ((M + splits - 1) / splits + T3_BK - 1) / T3_BK * T3_BK;
+    } else {
+        const int tiles = ((P + 127) / 128) * ((Q + 127) / 128);
+        // one resident round: 2 workgroups per CU (64 KB LDS each) = 2 x CUs slots; one workgroup more would run
+        // alone in a second round and double the launch time.  Every split is a multiple of BK rows.
+        splits = 2 * cus / tiles;
+        const int max_splits = (M + BK - 1) / BK;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        mps = ((M + splits - 1) / splits + BK - 1) / BK * BK;
+    }
+    splits = (M + mps - 1) / mps;  // every split has rows
+}
+
+static int tn_launch(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias, int tile,
+                     float* ws, long ws_floats, void* stream) {
     if (!Y || !X || !dW) return DCV_ERR_NULL;
     if (M <= 0 || P <= 0 || Q <= 0 || (P % 8) || (Q % 8)) return DCV_ERR_SHAPE;
     if ((ldy % 8) || (ldx % 8) || ((uintptr_t)Y & 15) || ((uintptr_t)X & 15)) return DCV_ERR_ALIGN;
@@ -1106,32 +1347,48 @@ extern "C" int dcv_gemm_tn_acc_ex(const void* Y, int ldy, const void* X, int ldx
     // (3 tiles x 85 splits: the fp32 atomic traffic grows faster than the operand traffic shrinks)
     const int pick = dcv_gemm_tn_pick(M, P, Q, tile);
     if (pick < 0) return pick;
-    if (pick == DCV_TILE_WIDE) {
-        const int tiles3 = (P / 384) * (Q / 128);
-        int splits3 = cus / tiles3;  // one 128 KB workgroup per CU, one resident round
-        const int max3 = (M + T3_BK - 1) / T3_BK;
-        if (splits3 > max3) splits3 = max3;
-        if (splits3 < 1) splits3 = 1;
-        const int mps3 = ((M + splits3 - 1) / splits3 + T3_BK - 1) / T3_BK * T3_BK;
-        splits3 = (M + mps3 - 1) / mps3;
-        GemmTnArgs a3{(const bf16_t*)Y, ldy, (const bf16_t*)X, ldx, M, P, Q, dW, lddw, dbias, mps3, splits3};
-        hipLaunchKernelGGL(gemm_tn384_kernel, dim3(tiles3 * splits3), dim3(512), 0, (hipStream_t)stream, a3);
-        DCV_LAUNCH_CHECK();
-        return DCV_OK;
+    int splits, mps;
+    tn_plan(M, P, Q, pick, cus, splits, mps);
+    const long stride = (long)P * Q + P;
+    if (ws) {
+        if (((uintptr_t)ws & 15) || (lddw % 4) || ((uintptr_t)dW & 15) || (dbias && ((uintptr_t)dbias & 15))) return DCV_ERR_ALIGN;
+        if (ws_floats < stride * splits) return DCV_ERR_SHAPE;
     }
-    const int tiles = ((P + 127) / 128) * ((Q + 127) / 128);
-    // one resident round: 2 workgroups per CU (64 KB LDS each) = 2 x CUs slots; one workgroup more would run
-    // alone in a second round and double the launch time.  Every split is a multiple of BK rows.
-    int splits = 2 * cus / tiles;
-    int max_splits = (M + BK - 1) / BK;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    int mps = ((M + splits - 1) / splits + BK - 1) / BK * BK;
-    splits = (M + mps - 1) / mps;
-    GemmTnArgs a{(const bf16_t*)Y, ldy, (const bf16_t*)X, ldx, M, P, Q, dW, lddw, dbias, mps, splits};
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 0, (hipStream_t)stream, a);
+    GemmTnArgs a{(const bf16_t*)Y, ldy, (const bf16_t*)X, ldx, M, P, Q, dW, lddw, dbias, mps, splits, ws, stride};
+    if (pick == DCV_TILE_WIDE) {
+        hipLaunchKernelGGL(gemm_tn384_kernel, dim3((P / 384) * (Q / 128) * splits), dim3(512), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(((P + 127) / 128) * ((Q + 127) / 128) * splits), dim3(256), 0, (hipStream_t)stream, a);
+    }
     DCV_LAUNCH_CHECK();
+    if (ws) {
+        const long n4 = (stride - (dbias ? 0 : P)) / 4;
+        int grid = (int)((n4 + 255) / 256);
+        if (grid > 4 * cus) grid = 4 * cus;
+        hipLaunchKernelGGL(det_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, splits, stride, dW, lddw, dbias, P, Q);
+        DCV_LAUNCH_CHECK();
+    }
     return DCV_OK;
+}
+
+extern "C" int dcv_gemm_tn_acc_ex(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,
+                                  float* dbias, int tile, void* stream) {
+    return tn_launch(Y, ldy, X, ldx, M, P, Q, dW, lddw, dbias, tile, nullptr, 0, stream);
+}
+
+extern "C" long dcv_gemm_tn_det_ws_floats(int M, int P, int Q, int tile) {
+    if (M <= 0 || P <= 0 || Q <= 0) return DCV_ERR_SHAPE;
+    const int pick = dcv_gemm_tn_pick(M, P, Q, tile);
+    if (pick < 0) return pick;
+    int splits, mps;
+    tn_plan(M, P, Q, pick, dcv_cu_count(), splits, mps);
+    return ((long)P * Q + P) * splits;
+}
+
+extern "C" int dcv_gemm_tn_acc_det(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,
+                                   float* dbias, int tile, float* ws, long ws_floats, void* stream) {
+    if (!ws) return DCV_ERR_NULL;
+    return tn_launch(Y, ldy, X, ldx, M, P, Q, dW, lddw, dbias, tile, ws, ws_floats, stream);
 }
 
 extern "C" int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,

@@ -291,25 +291,6 @@ extern "C" int dcv_fill_cls(float* x, const float* cls, const float* pos0, int B
     return DCV_OK;
 }
 
-// Measurement aid (tools/hog_probe.py): `wgs` workgroups that each hold a CU slot (256 threads, `lds_bytes` of LDS) for about
-// `kcycles` thousand clocks, like a communication kernel running beside the step.
-__global__ __launch_bounds__(256) void hog_kernel(int kcycles, unsigned* sink) {
-    extern __shared__ char hog_lds[];
-    const long long t0 = clock64();
-    unsigned x = threadIdx.x;
-    while (clock64() - t0 < (long long)kcycles * 1000) {
-        __builtin_amdgcn_s_sleep(32);
-        x = x * 1664525u + 1013904223u;
-    }
-    if (x == 0xFFFFFFFFu && sink) sink[0] = hog_lds[threadIdx.x];
-}
-extern "C" int dcv_debug_hog(int wgs, int lds_bytes, int kcycles, void* stream) {
-    if (wgs <= 0 || lds_bytes < 0 || kcycles <= 0) return DCV_ERR_SHAPE;
-    hipLaunchKernelGGL(hog_kernel, dim3(wgs), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, kcycles, (unsigned*)nullptr);
-    DCV_LAUNCH_CHECK();
-    return DCV_OK;
-}
-
 extern "C" int dcv_version(void) { return 100; }
 
 extern "C" const char* dcv_error_string(int code) {

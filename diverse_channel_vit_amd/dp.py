@@ -145,6 +145,22 @@ class DataParallel:
         self._callback_queued = False
         self.finalize()
 
+    def begin_forward(self) -> None:
+        """Called by the model at the start of every training forward.  The autograd engine skips its end-of-backward callbacks when a
+        backward pass raises (HIP error, out of memory, an exception in user code), which would leave `_callback_queued` set for good —
+        no later backward would queue finalize() and torch optimisers would read gradients whose all-reduces are still in flight.
+        A set flag here means exactly that: drain what the failed pass left behind and start clean."""
+        if self._callback_queued:
+            self._callback_queued = False
+            self._pending = None
+            self._deferred = []
+            for w, _, _ in self._works:
+                try:
+                    w.wait()
+                except Exception:  # the failed pass's collectives may have failed with it
+                    pass
+            self._works.clear()
+
     # ---- small parameters outside the encoder node --------------------------------------------------
     def hook_misc_params(self) -> None:
         """All-reduce the gradient of every parameter that is not part of the encoder arena as soon as

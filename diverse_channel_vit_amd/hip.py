@@ -18,7 +18,6 @@ TILE_AUTO, TILE_NARROW, TILE_WIDE = range(3)  # include/dcv.h DCV_TILE_*
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
     "dcv_version": ([], C.c_int),
-    "dcv_debug_hog": ([_i, _i, _i, _vp], _i),
     "dcv_error_string": ([_i], C.c_char_p),
     "dcv_gemm_nt": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp], _i),
     "dcv_gemm_nt_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp], _i),
@@ -26,6 +25,8 @@ _SIGS = {
     "dcv_gemm_tn_pick": ([_i, _i, _i, _i], _i),
     "dcv_gemm_tn_acc": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp], _i),
     "dcv_gemm_tn_acc_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp], _i),
+    "dcv_gemm_tn_det_ws_floats": ([_i, _i, _i, _i], _l),
+    "dcv_gemm_tn_acc_det": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp], _i),
     "dcv_ln_fwd": ([_vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp], _i),
     "dcv_ln_bwd": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp], _i),
     "dcv_attn_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
@@ -177,8 +178,16 @@ def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T
     _check(rc, "dcv_gemm_nt")
 
 
-def gemm_tn_acc(Y, X, dW, dbias=None, tile=TILE_AUTO):
-    """dW[P,Q] += Y[M,P]^T @ X[M,Q]; dbias[P] += colsum(Y)."""
+def gemm_tn_det_ws_floats(M, P, Q, tile=TILE_AUTO) -> int:
+    n = load().dcv_gemm_tn_det_ws_floats(M, P, Q, tile)
+    if n < 0:
+        _check(int(n), "dcv_gemm_tn_det_ws_floats")
+    return int(n)
+
+
+def gemm_tn_acc(Y, X, dW, dbias=None, tile=TILE_AUTO, ws=None):
+    """dW[P,Q] += Y[M,P]^T @ X[M,Q]; dbias[P] += colsum(Y).  ws (fp32 scratch of >= gemm_tn_det_ws_floats elements): the deterministic
+    form — partial tiles through ws, summed in a fixed order (dcv_gemm_tn_acc_det) — instead of fp32 atomics."""
     _req(Y, torch.bfloat16, "Y"); _req(X, torch.bfloat16, "X"); _req(dW, torch.float32, "dW")
     M, P = Y.shape
     Q = X.shape[1]
@@ -186,7 +195,11 @@ def gemm_tn_acc(Y, X, dW, dbias=None, tile=TILE_AUTO):
     lib = load()
     with _timer(lambda: ("gemm_tn384_kernel" if lib.dcv_gemm_tn_pick(M, P, Q, tile) == TILE_WIDE else "gemm_tn_kernel", f"M{M} P{P} Q{Q}",
                          2.0 * M * P * Q, None, 2.0 * M * (P + Q) + 8.0 * P * Q)):
-        rc = lib.dcv_gemm_tn_acc_ex(_p(Y), P, _p(X), Q, M, P, Q, _p(dW), Q, _p(dbias), tile, _stream())
+        if ws is None:
+            rc = lib.dcv_gemm_tn_acc_ex(_p(Y), P, _p(X), Q, M, P, Q, _p(dW), Q, _p(dbias), tile, _stream())
+        else:
+            _req(ws, torch.float32, "ws")
+            rc = lib.dcv_gemm_tn_acc_det(_p(Y), P, _p(X), Q, M, P, Q, _p(dW), Q, _p(dbias), tile, _p(ws), ws.numel(), _stream())
     _check(rc, "dcv_gemm_tn_acc")
 
 

@@ -65,6 +65,13 @@ int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile);
 int dcv_gemm_tn_pick(int M, int P, int Q, int tile);
 int dcv_gemm_tn_acc_ex(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias,
                        int tile, void* stream);
+/* DETERMINISTIC form (the reference trains with cudnn.deterministic = True, utils.py:394-401): the workgroups that split the token
+ * rows store their partial tiles to `ws` with plain stores and a second launch adds them to dW / dbias in a fixed order, so two runs on
+ * the same inputs give bit-identical gradients (dcv_gemm_tn_acc adds with fp32 atomics in dispatch order).  ws: caller-owned scratch of
+ * at least dcv_gemm_tn_det_ws_floats(M, P, Q, tile) floats, 16-byte aligned, contents irrelevant before and after; lddw % 4 == 0. */
+long dcv_gemm_tn_det_ws_floats(int M, int P, int Q, int tile);
+int dcv_gemm_tn_acc_det(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias,
+                        int tile, float* ws, long ws_floats, void* stream);
 
 /* LayerNorm (eps inside the sqrt, biased variance) — vit.py:361,374 / dichavit.py:651.
  * out is bf16 [M,D] (or f32 when out_is_f32); mean/rstd [M] may be NULL. x rows are x_row_stride floats apart. */
@@ -154,10 +161,6 @@ int dcv_cast_transpose_bf16(const float* src_base, void* dst_base, const long lo
 int dcv_cast_bf16_sr(const float* src, void* dst, long n, const unsigned* seed_dev, void* stream);
 int dcv_cast_transpose_bf16_sr(const float* src_base, void* dst_base, const long long* desc_dev, int n_desc, int max_tiles,
                                const unsigned* seed_dev, void* stream);
-
-/* measurement aid: `wgs` workgroups of 256 threads and `lds_bytes` of LDS each spin for ~kcycles*1000 clocks (a stand-in for a
- * communication kernel occupying CUs beside the step; tools/hog_probe.py) */
-int dcv_debug_hog(int wgs, int lds_bytes, int kcycles, void* stream);
 
 #ifdef __cplusplus
 }

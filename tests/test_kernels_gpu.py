@@ -196,6 +196,28 @@ def test_gemm_tn_headline_rows(hip, P, Q, tile):
     _check_gemm_tn(hip, HEADLINE_M, P, Q, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE)
 
 
+@pytest.mark.parametrize("tile", ["narrow", "wide"])
+@pytest.mark.parametrize("M,P,Q", [(HEADLINE_M, 1152, 384), (HEADLINE_M, 384, 1536), (4099, 384, 384), (700, 384, 256), (33, 384, 128)])
+def test_gemm_tn_deterministic(hip, M, P, Q, tile):
+    """dcv_gemm_tn_acc_det (the reference runs with cudnn.deterministic, utils.py:394-401): the splits store their
+    partial tiles to a workspace and a second launch adds them in a fixed order.  Same value as the reference product, bit-identical
+    from run to run (the atomic form is not), and the workspace may hold anything beforehand."""
+    t = hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE
+    nws = hip.gemm_tn_det_ws_floats(M, P, Q, t)
+    ws = torch.full((nws,), float("nan"), device="cuda")  # poisoned: every element the reducer reads must have been written
+    _check_gemm_tn(hip, M, P, Q, tile=t, ws=ws)
+    Y, X = _bf(M, P, seed=11), _bf(M, Q, seed=12)
+    runs = []
+    for rep in range(3):
+        dW, db = torch.zeros(P, Q, device="cuda"), torch.zeros(P, device="cuda")
+        ws.uniform_(-1e6, 1e6)
+        hip.gemm_tn_acc(Y, X, dW, db, tile=t, ws=ws)
+        runs.append((dW.clone(), db.clone()))
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    with pytest.raises(RuntimeError):  # a workspace that is too small is refused
+        hip.gemm_tn_acc(Y, X, dW, db, tile=t, ws=ws[: max(nws // 2, 4)])
+
+
 @pytest.mark.parametrize("M", [31, 32, 33, 1000, 4099])
 def test_gemm_tn_wide_ragged_reduction(hip, M):
     """384 x 128 kernel with reduction lengths around its 32-row stage (ragged last stage, fewer stages than the ring is deep)."""

@@ -1,10 +1,12 @@
 """How do the persistent one-round GEMM grids behave when another kernel holds some CUs (as RCCL's all-reduce does during the
-data-parallel backward)?  A hog kernel (dcv_debug_hog) occupies `wgs` CU slots on a side stream for ~3 ms; the GEMMs are timed on
+data-parallel backward)?  A hog kernel (tools/probes/hog_probe.hip, built into tools/probes/libhog_probe.so) occupies `wgs` CU slots on a side stream for ~3 ms; the GEMMs are timed on
 the main stream meanwhile."""
-import os, sys, json, torch
+import ctypes, os, sys, json, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diverse_channel_vit_amd import hip
 lib = hip.load()
+hog = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'probes', 'libhog_probe.so'))
+hog.hog_launch.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 B, N, H, D = 64, 1569, 6, 384; M = B * N
 torch.manual_seed(0)
 A = torch.randn(M, D, device="cuda").bfloat16(); W = (torch.randn(3 * D, D, device="cuda") * 0.05).bfloat16(); bias = torch.zeros(3 * D, device="cuda"); out = torch.empty(M, 3 * D, dtype=torch.bfloat16, device="cuda")
@@ -18,7 +20,7 @@ def timed(fn, wgs, lds):
     torch.cuda.synchronize()
     if wgs:
         with torch.cuda.stream(side):
-            lib.dcv_debug_hog(wgs, lds, 8000, side.cuda_stream)  # ~4 ms
+            hog.hog_launch(wgs, lds, 8000, side.cuda_stream)  # ~4 ms
         import time; time.sleep(0.0005)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

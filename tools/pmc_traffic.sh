@@ -5,9 +5,11 @@ set -e
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/${1:-r02_v1}; mkdir -p $OUT
 cd $ROOT && timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err && tail -1 $OUT/bench.json | cut -c1-200
 cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/dcvstats
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dcvstats -o s -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > $OUT/stats.log 2>&1 && echo stats done
 find /tmp/dcvstats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf "/tmp/dcvpmc_${c}"
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/dcvpmc_$c -o p -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $OUT/pmc_$c.log 2>&1 && echo "$c done"
 done
 DCV_OUT=${1:-r02_v1} python3 - <<'PY'

@@ -6,7 +6,7 @@ cd /tmp; export TMPDIR=/tmp
 for lib in "$@"; do
   name=$(basename $lib .so)
   for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf /tmp/tnpmc_$name_$c
+    rm -rf "/tmp/tnpmc_${name}_${c}"
     TB_ROUNDS=3 timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/tnpmc_${name}_$c -o p -- python3 $ROOT/tools/tn_bench.py $ROOT/$lib > $OUT/pmc_${name}_$c.log 2>&1
   done
   python3 - "$name" >> $OUT/tn_pmc.txt <<'PY'
