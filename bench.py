@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--img", type=int, default=224)
     ap.add_argument("--classes", type=int, default=161)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--atomic-reductions", action="store_true", help="cross-workgroup sums with fp32 atomics (set_deterministic(False)) instead of the default "
+                    "deterministic forms (partials through workspaces, fixed-order second pass; bit-reproducible gradients, +0.7 %% step time)")
     ap.add_argument("--kernel-table", action="store_true", help="also print the per-symbol table to stderr")
     ap.add_argument("--graph", action="store_true", help="N=1: replay a HIP-graph capture of the step (about 1 %% faster than eager launches); the "
                                                          "dominant kernel's events then come from the profiled warm-up steps, not from the timed region")
@@ -184,6 +186,8 @@ def main():
     import diverse_channel_vit_amd as dcv
     from diverse_channel_vit_amd import hip
     hip.load()
+    if args.atomic_reductions:
+        hip.set_deterministic(False)
 
     if args.chammi:
         args.channels, args.classes = 12, 14
@@ -430,6 +434,8 @@ def main():
                        "host_syncs_per_step": 0,
                        "launch": "hip-graph replay of the captured step" if use_graph else "eager",
                        "wgrad_stream": bool(model.wgrad_stream),
+                       "reductions": ("deterministic: partial sums through workspaces, fixed-order second pass (bit-reproducible gradients)"
+                                      if hip.is_deterministic() else "fp32 atomics (order-dependent in the last bits; --atomic-reductions)"),
                        **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)",
                            # the secondary run reports tokens/s too.  Tokens of a step = batch * (1 + C_step * n); the sum of
                            # C_step over the timed steps is the growth of the model's channel histogram (patch_embed.counter)

@@ -10,6 +10,7 @@ from .dp import DataParallel  # noqa: F401
 from .optim import HipAdamW, clip_grad_norm_  # noqa: F401
 from .checkpoint import save_checkpoint, load_checkpoint, evaluate, dump_features, eval_subset_channels  # noqa: F401
 from .graph import GraphedTrainStep  # noqa: F401
+from .hip import set_deterministic, is_deterministic  # noqa: F401
 
 __all__ = ["DiChaViT", "dichavit", "proxy_loss", "DataParallel", "HipAdamW", "GraphedTrainStep", "clip_grad_norm_", "save_checkpoint", "load_checkpoint",
-           "evaluate", "dump_features", "eval_subset_channels"]
+           "evaluate", "dump_features", "eval_subset_channels", "set_deterministic", "is_deterministic"]

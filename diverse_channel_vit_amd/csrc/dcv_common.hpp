@@ -195,3 +195,95 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
 }
+
+// ---- deterministic mode (the reference trains with cudnn.deterministic = True, utils.py:394-401) -------------------------------
+// Kernels that combine partial sums of several workgroups have a second form that STORES the partials to a caller-supplied
+// workspace instead of adding them atomically; this kernel then adds them to the destination in index order — a fixed summation
+// order whatever the dispatch order was, so two runs on the same inputs are bit-identical.  Column c of a part goes to
+// dstA[(c / QA) * ldA + c % QA] for c < nA and to dstB[c - nA] for nA <= c < nA + nB.  VEC: four columns per thread (all of nA, QA,
+// ldA, nB, part_stride multiples of 4 and 16-byte aligned pointers).
+template <bool VEC>
+static __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int nparts, long part_stride,
+                                                                float* __restrict__ dstA, long nA, int QA, long ldA,
+                                                                float* __restrict__ dstB, long nB) {
+    constexpr int W = VEC ? 4 : 1;
+    const long nv = (nA + nB) / W;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) {
+        const long c = v * W;
+        float s[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) s[e] = 0.f;
+        const float* src = part + c;
+        for (int k = 0; k < nparts; ++k) {
+            if constexpr (VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (size_t)k * part_stride);
+                s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+            } else {
+                s[0] += src[(size_t)k * part_stride];
+            }
+        }
+        float* d = (c < nA) ? dstA + (c / QA) * ldA + (c % QA) : dstB + (c - nA);
+#pragma unroll
+        for (int e = 0; e < W; ++e) d[e] += s[e];
+    }
+}
+// Same sum for MANY parts of FEW columns (LayerNorm: 1024 parts x 768 columns; one thread per column group would walk all parts alone):
+// a workgroup owns 16 column groups; part lane pl = thread / 16 adds parts pl, pl + 16, pl + 32, ... in increasing order, the 16 lane sums
+// are then added in lane order by the threads of lane 0.  The association order is fixed by (nparts) alone: deterministic.
+template <bool VEC>
+static __global__ __launch_bounds__(256) void det_reduce_tall_kernel(const float* __restrict__ part, int nparts, long part_stride,
+                                                                     float* __restrict__ dstA, long nA, int QA, long ldA,
+                                                                     float* __restrict__ dstB, long nB) {
+    constexpr int W = VEC ? 4 : 1;
+    __shared__ float red[16][16][W];
+    const int pl = threadIdx.x >> 4, cg = threadIdx.x & 15;
+    const long nv = (nA + nB) / W;
+    const long v = (long)blockIdx.x * 16 + cg;
+    float s[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) s[e] = 0.f;
+    if (v < nv) {
+        const float* src = part + v * W;
+        for (int k = pl; k < nparts; k += 16) {
+            if constexpr (VEC) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (size_t)k * part_stride);
+                s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+            } else {
+                s[0] += src[(size_t)k * part_stride];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) red[pl][cg][e] = s[e];
+    __syncthreads();
+    if (pl == 0 && v < nv) {
+        const long c = v * W;
+        float* d = (c < nA) ? dstA + (c / QA) * ldA + (c % QA) : dstB + (c - nA);
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float t = 0.f;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) t += red[l][cg][e];
+            d[e] += t;
+        }
+    }
+}
+// launches the reduction; returns false when the launch failed
+static inline bool det_reduce(const float* part, int nparts, long part_stride, float* dstA, long nA, int QA, long ldA, float* dstB, long nB,
+                              hipStream_t s) {
+    const bool vec = !(nA & 3) && !(QA & 3) && !(ldA & 3) && !(nB & 3) && !(part_stride & 3) && !((uintptr_t)part & 15) &&
+                     !((uintptr_t)dstA & 15) && !((uintptr_t)dstB & 15);
+    const long nv = (nA + nB) / (vec ? 4 : 1);
+    if (nparts >= 32 && nv <= 16384) {  // many parts, few columns
+        const unsigned grid = (unsigned)((nv + 15) / 16);
+        if (vec) hipLaunchKernelGGL(det_reduce_tall_kernel<true>, dim3(grid), dim3(256), 0, s, part, nparts, part_stride, dstA, nA, QA, ldA, dstB, nB);
+        else hipLaunchKernelGGL(det_reduce_tall_kernel<false>, dim3(grid), dim3(256), 0, s, part, nparts, part_stride, dstA, nA, QA, ldA, dstB, nB);
+        return hipGetLastError() == hipSuccess;
+    }
+    long grid = (nv + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    if (grid < 1) grid = 1;
+    if (vec) hipLaunchKernelGGL(det_reduce_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, part, nparts, part_stride, dstA, nA, QA, ldA, dstB, nB);
+    else hipLaunchKernelGGL(det_reduce_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, part, nparts, part_stride, dstA, nA, QA, ldA, dstB, nB);
+    return hipGetLastError() == hipSuccess;
+}

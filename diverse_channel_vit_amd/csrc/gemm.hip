@@ -1181,26 +1181,6 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
     }
 }
 
-// Deterministic mode, second pass: dst[c] += part[0][c] + part[1][c] + ... in THAT order (a fixed summation order whatever the dispatch
-// order was), four columns per thread.  Columns [0, P*Q) are the weight gradient (row stride lddw), [P*Q, P*Q + P) the bias gradient.
-__global__ __launch_bounds__(256) void det_reduce_kernel(const float* __restrict__ part, int nparts, long part_stride, float* __restrict__ dW,
-                                                         int lddw, float* __restrict__ dbias, int P, int Q) {
-    const long pq = (long)P * Q, n4 = (pq + (dbias ? P : 0)) >> 2;
-    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < n4; v += (long)gridDim.x * 256) {
-        const long c = v << 2;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* src = part + c;
-        for (int k = 0; k < nparts; ++k) {
-            const float4 t = *reinterpret_cast<const float4*>(src + (size_t)k * part_stride);
-            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
-        }
-        float* d = (c < pq) ? dW + (c / Q) * (long)lddw + (c % Q) : dbias + (c - pq);
-        float4 o = *reinterpret_cast<float4*>(d);
-        o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
-        *reinterpret_cast<float4*>(d) = o;
-    }
-}
-
 }  // namespace
 
 // CU count of the current device, queried once per device (an immutable device property, cached; no allocation, no sync)
@@ -1362,11 +1342,7 @@ static int tn_launch(const void* Y, int ldy, const void* X, int ldx, int M, int 
     }
     DCV_LAUNCH_CHECK();
     if (ws) {
-        const long n4 = (stride - (dbias ? 0 : P)) / 4;
-        int grid = (int)((n4 + 255) / 256);
-        if (grid > 4 * cus) grid = 4 * cus;
-        hipLaunchKernelGGL(det_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, splits, stride, dW, lddw, dbias, P, Q);
-        DCV_LAUNCH_CHECK();
+        if (!det_reduce(ws, splits, stride, dW, (long)P * Q, Q, lddw, dbias, dbias ? P : 0, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
     }
     return DCV_OK;
 }

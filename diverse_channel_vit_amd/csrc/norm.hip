@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du
                                                      const float* __restrict__ gamma, const float* dx_in, float* dx_out,
                                                      bf16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int D, long x_row_stride,
-                                                     long dx_row_stride) {
+                                                     long dx_row_stride, float* __restrict__ part) {
+    // part != nullptr (deterministic mode): workgroup b stores its column sums to part[b][2][D] instead of adding them atomically
     __shared__ float red[4][2][MAXV * 64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = D >> 2;
@@ -210,8 +211,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du
             sg += red[w][0][slot];
             sb += red[w][1][slot];
         }
-        atomicAdd(dgamma + c, sg);
-        atomicAdd(dbeta + c, sb);
+        if (part) {
+            part[(size_t)blockIdx.x * 2 * D + c] = sg;
+            part[(size_t)blockIdx.x * 2 * D + D + c] = sb;
+        } else {
+            atomicAdd(dgamma + c, sg);
+            atomicAdd(dbeta + c, sb);
+        }
     }
 }
 
@@ -237,16 +243,20 @@ extern "C" int dcv_ln_fwd(const float* x, long x_row_stride, const float* gamma,
     return DCV_OK;
 }
 
-extern "C" int dcv_ln_bwd(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
-                          const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
-                          float* dbeta, int M, int D, void* stream) {
+static int ln_bwd_grid(int M) {
+    int grid = (M + 3) / 4;
+    return grid > 1024 ? 1024 : grid;
+}
+static int ln_bwd_launch(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
+                         const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
+                         float* dbeta, int M, int D, float* ws, long ws_floats, void* stream) {
     if (!du || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta) return DCV_ERR_NULL;
     if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAXV_MAX || (x_row_stride & 3) || (dx_row_stride & 3)) return DCV_ERR_SHAPE;
-    int grid = (M + 3) / 4;
-    if (grid > 1024) grid = 1024;
+    const int grid = ln_bwd_grid(M);
+    if (ws && ws_floats < (long)grid * 2 * D) return DCV_ERR_SHAPE;
 #define DCV_LN_BWD(F32, V)                                                                                                          \
     hipLaunchKernelGGL((ln_bwd_kernel<F32, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, du, x, mean, rstd, gamma, dx_in, dx_out, \
-                       (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride)
+                       (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride, ws)
     if (D <= 512) {
         if (du_is_f32) DCV_LN_BWD(true, 2);
         else DCV_LN_BWD(false, 2);
@@ -256,5 +266,21 @@ extern "C" int dcv_ln_bwd(const void* du, int du_is_f32, const float* x, long x_
     }
 #undef DCV_LN_BWD
     DCV_LAUNCH_CHECK();
+    if (ws && !det_reduce(ws, grid, 2L * D, dgamma, D, D, D, dbeta, D, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
     return DCV_OK;
+}
+
+extern "C" int dcv_ln_bwd(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
+                          const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
+                          float* dbeta, int M, int D, void* stream) {
+    return ln_bwd_launch(du, du_is_f32, x, x_row_stride, mean, rstd, gamma, dx_in, dx_out, dx_row_stride, dx_bf16, dgamma, dbeta, M, D,
+                         nullptr, 0, stream);
+}
+extern "C" long dcv_ln_bwd_det_ws_floats(int M, int D) { return (M <= 0 || D <= 0) ? DCV_ERR_SHAPE : (long)ln_bwd_grid(M) * 2 * D; }
+extern "C" int dcv_ln_bwd_det(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
+                              const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
+                              float* dbeta, int M, int D, float* ws, long ws_floats, void* stream) {
+    if (!ws) return DCV_ERR_NULL;
+    return ln_bwd_launch(du, du_is_f32, x, x_row_stride, mean, rstd, gamma, dx_in, dx_out, dx_row_stride, dx_bf16, dgamma, dbeta, M, D,
+                         ws, ws_floats, stream);
 }

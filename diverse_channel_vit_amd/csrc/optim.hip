@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 }
 
 // sum of squares of a flat fp32 range, added to *acc (one atomic per block)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n4, long n, float* __restrict__ acc) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n4, long n, float* __restrict__ acc,
+                                                    float* __restrict__ part) {
     const long stride = (long)gridDim.x * 256;
     float s = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -134,10 +135,13 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
         for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) s += x[i] * x[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        if (part) part[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];  // deterministic mode: summed in block order by det_reduce
+        else atomicAdd(acc, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    }
 }
 
 // x *= min(1, max_norm / (sqrt(*sumsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_'s coefficient, read from device memory)
@@ -257,17 +261,27 @@ extern "C" int dcv_cast_transpose_bf16_sr(const float* src_base, void* dst_base,
     return DCV_OK;
 }
 
-extern "C" int dcv_sumsq_acc(const float* x, long n, float* acc, void* stream) {
+static long sumsq_grid(long n) {
+    long grid = (n / 4 + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    return grid < 1 ? 1 : grid;
+}
+static int sumsq_launch(const float* x, long n, float* acc, float* ws, long ws_floats, void* stream) {
     if (!x || !acc) return DCV_ERR_NULL;
     if (n <= 0) return DCV_ERR_SHAPE;
     if ((uintptr_t)x & 15) return DCV_ERR_ALIGN;
-    long n4 = n / 4;
-    long grid = (n4 + 255) / 256;
-    if (grid > 1024) grid = 1024;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n4, n, acc);
+    const long grid = sumsq_grid(n);
+    if (ws && ws_floats < grid) return DCV_ERR_SHAPE;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, n / 4, n, acc, ws);
     DCV_LAUNCH_CHECK();
+    if (ws && !det_reduce(ws, (int)grid, 1, acc, 1, 1, 1, nullptr, 0, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
     return DCV_OK;
+}
+extern "C" int dcv_sumsq_acc(const float* x, long n, float* acc, void* stream) { return sumsq_launch(x, n, acc, nullptr, 0, stream); }
+extern "C" long dcv_sumsq_det_ws_floats(long n) { return n <= 0 ? DCV_ERR_SHAPE : sumsq_grid(n); }
+extern "C" int dcv_sumsq_acc_det(const float* x, long n, float* acc, float* ws, long ws_floats, void* stream) {
+    if (!ws) return DCV_ERR_NULL;
+    return sumsq_launch(x, n, acc, ws, ws_floats, stream);
 }
 
 extern "C" int dcv_clip_scale(float* x, long n, const float* sumsq_dev, float max_norm, void* stream) {

@@ -60,7 +60,9 @@ constexpr int PB_IT = 2;  // positions per workgroup
 __global__ __launch_bounds__(256) void patch_bwd_kernel(const float* __restrict__ dx0, const float* __restrict__ dYloss,
                                                         bf16_t* __restrict__ dYb, float* __restrict__ dE,
                                                         float* __restrict__ dpos, float* __restrict__ dcls, int B, int C,
-                                                        int n, int D) {
+                                                        int n, int D, float* __restrict__ partE, float* __restrict__ partP) {
+    // partE / partP != nullptr (deterministic mode): the per-workgroup sums for d(channel_embed) and d(pos[1:]) are stored —
+    // partE[(position block * bpar + bsub)][C * D], partP[(channel * bpar + bsub)][n * D] — and added up in index order by det_reduce
     const int nv = D >> 2;
     const int T = C * n;
     const int c = blockIdx.y;
@@ -106,14 +108,23 @@ __global__ __launch_bounds__(256) void patch_bwd_kernel(const float* __restrict_
                 }
             }
         }
-        float* pe = dE + (size_t)c * D + v * 4;
-        atomicAdd(pe, aE.x); atomicAdd(pe + 1, aE.y); atomicAdd(pe + 2, aE.z); atomicAdd(pe + 3, aE.w);
+        if (partE) {
+            reinterpret_cast<float4*>(partE + ((size_t)blockIdx.x * bpar + bsub) * C * D + (size_t)c * D)[v] = aE;
 #pragma unroll
-        for (int k = 0; k < PB_IT; ++k) {
-            int i = i0 + k;
-            if (i < n) {
-                float* pp = dpos + (size_t)(1 + i) * D + v * 4;
-                atomicAdd(pp, aP[k].x); atomicAdd(pp + 1, aP[k].y); atomicAdd(pp + 2, aP[k].z); atomicAdd(pp + 3, aP[k].w);
+            for (int k = 0; k < PB_IT; ++k) {
+                int i = i0 + k;
+                if (i < n) reinterpret_cast<float4*>(partP + ((size_t)c * bpar + bsub) * n * D + (size_t)i * D)[v] = aP[k];
+            }
+        } else {
+            float* pe = dE + (size_t)c * D + v * 4;
+            atomicAdd(pe, aE.x); atomicAdd(pe + 1, aE.y); atomicAdd(pe + 2, aE.z); atomicAdd(pe + 3, aE.w);
+#pragma unroll
+            for (int k = 0; k < PB_IT; ++k) {
+                int i = i0 + k;
+                if (i < n) {
+                    float* pp = dpos + (size_t)(1 + i) * D + v * 4;
+                    atomicAdd(pp, aP[k].x); atomicAdd(pp + 1, aP[k].y); atomicAdd(pp + 2, aP[k].z); atomicAdd(pp + 3, aP[k].w);
+                }
             }
         }
     }
@@ -125,7 +136,8 @@ constexpr int ORTHO_CHUNK = 28;  // tokens per workgroup (4 waves x 7)
 
 __global__ __launch_bounds__(256) void ortho_fwd_partial(const float* __restrict__ Y, float* __restrict__ S,
                                                          float* __restrict__ selfsq, float* __restrict__ inv_norm, int C,
-                                                         int n, int D) {
+                                                         int n, int D, float* __restrict__ part) {
+    // part != nullptr (deterministic mode): token chunk k stores its sums to part[k][B*C*D + B*C] (S columns, then selfsq)
     __shared__ float red[4][OV * 64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bc = blockIdx.y;  // b*C + c
@@ -160,8 +172,15 @@ __global__ __launch_bounds__(256) void ortho_fwd_partial(const float* __restrict
     __shared__ float red_ss[4];
     if (lane == 0) red_ss[wave] = ss;
     __syncthreads();
-    for (int c = threadIdx.x; c < D; c += 256) atomicAdd(S + (size_t)bc * D + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
-    if (threadIdx.x == 0) atomicAdd(selfsq + bc, red_ss[0] + red_ss[1] + red_ss[2] + red_ss[3]);
+    if (part) {
+        const size_t BC = gridDim.y;
+        float* pk = part + (size_t)blockIdx.x * (BC * D + BC);
+        for (int c = threadIdx.x; c < D; c += 256) pk[(size_t)bc * D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        if (threadIdx.x == 0) pk[BC * D + bc] = red_ss[0] + red_ss[1] + red_ss[2] + red_ss[3];
+    } else {
+        for (int c = threadIdx.x; c < D; c += 256) atomicAdd(S + (size_t)bc * D + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+        if (threadIdx.x == 0) atomicAdd(selfsq + bc, red_ss[0] + red_ss[1] + red_ss[2] + red_ss[3]);
+    }
 }
 
 // zero the two atomic accumulators (a kernel, not hipMemsetAsync: memset nodes did not replay correctly when the
@@ -306,32 +325,71 @@ extern "C" int dcv_im2col_bf16(const void* x, int x_is_u8, const int* ch_idx, co
     return DCV_OK;
 }
 
-extern "C" int dcv_patch_bwd(const float* dx0, const float* dYloss, void* dY_bf16, float* dE, float* dpos, float* dcls, int B, int C,
-                             int n, int D, void* stream) {
+static int patch_bwd_launch(const float* dx0, const float* dYloss, void* dY_bf16, float* dE, float* dpos, float* dcls, int B, int C, int n,
+                            int D, float* ws, long ws_floats, void* stream) {
     if (!dx0 || !dY_bf16 || !dE || !dpos || !dcls) return DCV_ERR_NULL;
     if (B <= 0 || C <= 0 || n <= 0 || D <= 0 || (D & 3) || D > 1024) return DCV_ERR_SHAPE;
     dim3 grid((n + PB_IT - 1) / PB_IT, C + 1);
-    hipLaunchKernelGGL(patch_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dx0, dYloss, (bf16_t*)dY_bf16, dE, dpos, dcls, B, C, n, D);
+    const int bpar = 256 / (D >> 2);
+    const long nE = (long)grid.x * bpar * C * D, nP = (long)C * bpar * n * D;
+    if (ws && ws_floats < nE + nP) return DCV_ERR_SHAPE;
+    // a position block whose last position does not exist leaves its partP slot unwritten only for i >= n, which is outside [0, n)
+    hipLaunchKernelGGL(patch_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dx0, dYloss, (bf16_t*)dY_bf16, dE, dpos, dcls, B, C, n, D,
+                       ws, ws ? ws + nE : nullptr);
     DCV_LAUNCH_CHECK();
+    if (ws) {
+        // rows with bsub >= B never run the batch loop but still store their (zero) sums: every slot of both part arrays is written
+        if (!det_reduce(ws, (int)grid.x * bpar, (long)C * D, dE, (long)C * D, D, D, nullptr, 0, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
+        if (!det_reduce(ws + nE, C * bpar, (long)n * D, dpos + D, (long)n * D, D, D, nullptr, 0, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
+    }
     return DCV_OK;
 }
+extern "C" int dcv_patch_bwd(const float* dx0, const float* dYloss, void* dY_bf16, float* dE, float* dpos, float* dcls, int B, int C,
+                             int n, int D, void* stream) {
+    return patch_bwd_launch(dx0, dYloss, dY_bf16, dE, dpos, dcls, B, C, n, D, nullptr, 0, stream);
+}
+extern "C" long dcv_patch_bwd_det_ws_floats(int B, int C, int n, int D) {
+    if (B <= 0 || C <= 0 || n <= 0 || D <= 0 || (D & 3) || D > 1024) return DCV_ERR_SHAPE;
+    const long bpar = 256 / (D >> 2);
+    return (long)((n + PB_IT - 1) / PB_IT) * bpar * C * D + (long)C * bpar * n * D;
+}
+extern "C" int dcv_patch_bwd_det(const float* dx0, const float* dYloss, void* dY_bf16, float* dE, float* dpos, float* dcls, int B, int C,
+                                 int n, int D, float* ws, long ws_floats, void* stream) {
+    if (!ws) return DCV_ERR_NULL;
+    return patch_bwd_launch(dx0, dYloss, dY_bf16, dE, dpos, dcls, B, C, n, D, ws, ws_floats, stream);
+}
 
-extern "C" int dcv_ortho_fwd(const float* Y, float* S, float* selfsq, float* tot, float* inv_norm, float* stats, int B, int C, int n,
-                             int D, void* stream) {
+static int ortho_fwd_launch(const float* Y, float* S, float* selfsq, float* tot, float* inv_norm, float* stats, int B, int C, int n, int D,
+                            float* ws, long ws_floats, void* stream) {
     if (!Y || !S || !selfsq || !tot || !inv_norm || !stats) return DCV_ERR_NULL;
     if (B <= 0 || C <= 0 || n <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * OV) return DCV_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    dim3 grid((n + ORTHO_CHUNK - 1) / ORTHO_CHUNK, B * C);
+    const long nS = (long)B * C * D, nQ = (long)B * C;
+    if (ws && ws_floats < (long)grid.x * (nS + nQ)) return DCV_ERR_SHAPE;
     {
-        const long nS = (long)B * C * D, nQ = (long)B * C;
         long zg = (nS + 255) / 256;
         if (zg > 1024) zg = 1024;
         hipLaunchKernelGGL(ortho_zero_kernel, dim3((unsigned)zg), dim3(256), 0, s, S, nS, selfsq, nQ);
     }
-    dim3 grid((n + ORTHO_CHUNK - 1) / ORTHO_CHUNK, B * C);
-    hipLaunchKernelGGL(ortho_fwd_partial, grid, dim3(256), 0, s, Y, S, selfsq, inv_norm, C, n, D);
+    hipLaunchKernelGGL(ortho_fwd_partial, grid, dim3(256), 0, s, Y, S, selfsq, inv_norm, C, n, D, ws);
+    if (ws && !det_reduce(ws, (int)grid.x, nS + nQ, S, nS, D, D, selfsq, nQ, s)) return DCV_ERR_LAUNCH;
     hipLaunchKernelGGL(ortho_fwd_final, dim3(B), dim3(256), 0, s, S, selfsq, tot, stats, C, D);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
+}
+extern "C" int dcv_ortho_fwd(const float* Y, float* S, float* selfsq, float* tot, float* inv_norm, float* stats, int B, int C, int n,
+                             int D, void* stream) {
+    return ortho_fwd_launch(Y, S, selfsq, tot, inv_norm, stats, B, C, n, D, nullptr, 0, stream);
+}
+extern "C" long dcv_ortho_fwd_det_ws_floats(int B, int C, int n, int D) {
+    if (B <= 0 || C <= 0 || n <= 0 || D <= 0) return DCV_ERR_SHAPE;
+    return (long)((n + ORTHO_CHUNK - 1) / ORTHO_CHUNK) * ((long)B * C * D + (long)B * C);
+}
+extern "C" int dcv_ortho_fwd_det(const float* Y, float* S, float* selfsq, float* tot, float* inv_norm, float* stats, int B, int C, int n,
+                                 int D, float* ws, long ws_floats, void* stream) {
+    if (!ws) return DCV_ERR_NULL;
+    return ortho_fwd_launch(Y, S, selfsq, tot, inv_norm, stats, B, C, n, D, ws, ws_floats, stream);
 }
 
 extern "C" int dcv_ortho_bwd(const float* Y, const float* S, const float* tot, const float* inv_norm, const float* coef, float* dY,

@@ -29,6 +29,14 @@ _SIGS = {
     "dcv_gemm_tn_acc_det": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp], _i),
     "dcv_ln_fwd": ([_vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp], _i),
     "dcv_ln_bwd": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp], _i),
+    "dcv_ln_bwd_det_ws_floats": ([_i, _i], _l),
+    "dcv_ln_bwd_det": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp, _l, _vp], _i),
+    "dcv_patch_bwd_det_ws_floats": ([_i, _i, _i, _i], _l),
+    "dcv_patch_bwd_det": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp], _i),
+    "dcv_ortho_fwd_det_ws_floats": ([_i, _i, _i, _i], _l),
+    "dcv_ortho_fwd_det": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp], _i),
+    "dcv_sumsq_det_ws_floats": ([_l], _l),
+    "dcv_sumsq_acc_det": ([_vp, _l, _vp, _vp, _l, _vp], _i),
     "dcv_attn_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_delta": ([_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
@@ -155,6 +163,42 @@ def _req(t: torch.Tensor, dtype, name: str):
 
 
 # ---------------------------------------------------------------------------------------------
+# Deterministic mode — the DEFAULT since round 3 (the reference's trainer sets cudnn.deterministic = True, utils.py:394-401).  Every entry
+# that would add partial sums of several workgroups with atomics runs in its *_det form: partials through a workspace, summed in a
+# fixed order by a second launch — a training step is bit-reproducible.  Cost measured on the headline step: 35.52 -> 35.78 ms (+0.7 %; the
+# weight-gradient GEMMs are 5-7 % FASTER with plain partial stores + one reduction pass than with their fp32-atomic flush, LayerNorm's
+# 23 extra reduction launches cost the rest).  set_deterministic(False) / DCV_DETERMINISTIC=0 selects the atomic forms.  One workspace per
+# (device, stream), grown on demand; kernels on one stream run in order, so they can share it.
+_deterministic = os.environ.get("DCV_DETERMINISTIC", "1") not in ("0", "", "false", "False")
+_det_ws = {}
+
+
+def set_deterministic(on: bool = True) -> bool:
+    """Returns the previous setting."""
+    global _deterministic
+    old, _deterministic = _deterministic, bool(on)
+    return old
+
+
+def is_deterministic() -> bool:
+    return _deterministic
+
+
+def _workspace(n_floats: int, like: torch.Tensor) -> torch.Tensor:
+    key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream)
+    ws = _det_ws.get(key)
+    if ws is None or ws.numel() < n_floats:
+        ws = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=like.device)
+        _det_ws[key] = ws
+    return ws
+
+
+def _ws_size(n) -> int:
+    if n < 0:
+        _check(int(n), "det workspace size")
+    return int(n)
+
+
 def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T=0, n=0, ldo=None, ldo2=None, ldaux=None,
             grid_cap=0, tile=TILE_AUTO):
     """C = A[M,K] @ W[N,K]^T with the given epilogue (see include/dcv.h).  grid_cap / tile: dcv_gemm_nt_ex's launch controls."""
@@ -193,6 +237,8 @@ def gemm_tn_acc(Y, X, dW, dbias=None, tile=TILE_AUTO, ws=None):
     Q = X.shape[1]
     assert X.shape[0] == M and dW.numel() == P * Q
     lib = load()
+    if ws is None and _deterministic:
+        ws = _workspace(_ws_size(lib.dcv_gemm_tn_det_ws_floats(M, P, Q, tile)), dW)
     with _timer(lambda: ("gemm_tn384_kernel" if lib.dcv_gemm_tn_pick(M, P, Q, tile) == TILE_WIDE else "gemm_tn_kernel", f"M{M} P{P} Q{Q}",
                          2.0 * M * P * Q, None, 2.0 * M * (P + Q) + 8.0 * P * Q)):
         if ws is None:
@@ -214,9 +260,15 @@ def ln_fwd(x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride=None):
 def ln_bwd(du, x, mean, rstd, gamma, dx_in, dx_out, dx_bf16, dgamma, dbeta, M, D, x_row_stride=None, dx_row_stride=None):
     with _timer(lambda: (f"ln_bwd_kernel<{'true' if du.dtype == torch.float32 else 'false'}, {2 if D <= 512 else 4}>", f"M{M} D{D}", 0.0, None,
                          M * D * ((4.0 if du.dtype == torch.float32 else 2.0) + 4.0 + (4.0 if dx_in is not None else 0.0) + 4.0 + (2.0 if dx_bf16 is not None else 0.0)))):
-        rc = load().dcv_ln_bwd(_p(du), 1 if du.dtype == torch.float32 else 0, _p(x), D if x_row_stride is None else x_row_stride,
-                               _p(mean), _p(rstd), _p(gamma), _p(dx_in), _p(dx_out), D if dx_row_stride is None else dx_row_stride,
-                               _p(dx_bf16), _p(dgamma), _p(dbeta), M, D, _stream())
+        lib = load()
+        args = (_p(du), 1 if du.dtype == torch.float32 else 0, _p(x), D if x_row_stride is None else x_row_stride,
+                _p(mean), _p(rstd), _p(gamma), _p(dx_in), _p(dx_out), D if dx_row_stride is None else dx_row_stride,
+                _p(dx_bf16), _p(dgamma), _p(dbeta), M, D)
+        if _deterministic:
+            ws = _workspace(_ws_size(lib.dcv_ln_bwd_det_ws_floats(M, D)), dx_out)
+            rc = lib.dcv_ln_bwd_det(*args, _p(ws), ws.numel(), _stream())
+        else:
+            rc = lib.dcv_ln_bwd(*args, _stream())
     _check(rc, "dcv_ln_bwd")
 
 
@@ -256,7 +308,13 @@ def im2col(x, ch_idx, out, B, Ct, C, H, W, P, scale=None, shift=None):
 
 
 def patch_bwd(dx0, dYloss, dY_bf16, dE, dpos, dcls, B, C, n, D):
-    _check(load().dcv_patch_bwd(_p(dx0), _p(dYloss), _p(dY_bf16), _p(dE), _p(dpos), _p(dcls), B, C, n, D, _stream()), "dcv_patch_bwd")
+    lib = load()
+    if _deterministic:
+        ws = _workspace(_ws_size(lib.dcv_patch_bwd_det_ws_floats(B, C, n, D)), dx0)
+        rc = lib.dcv_patch_bwd_det(_p(dx0), _p(dYloss), _p(dY_bf16), _p(dE), _p(dpos), _p(dcls), B, C, n, D, _p(ws), ws.numel(), _stream())
+    else:
+        rc = lib.dcv_patch_bwd(_p(dx0), _p(dYloss), _p(dY_bf16), _p(dE), _p(dpos), _p(dcls), B, C, n, D, _stream())
+    _check(rc, "dcv_patch_bwd")
 
 
 def gather_tokens(x, idx, out, B, N, Nk, D, scatter=False):
@@ -268,7 +326,13 @@ def fill_cls(x, cls, pos0, B, batch_stride, D):
 
 
 def ortho_fwd(Y, S, selfsq, tot, inv_norm, stats, B, Cc, n, D):
-    _check(load().dcv_ortho_fwd(_p(Y), _p(S), _p(selfsq), _p(tot), _p(inv_norm), _p(stats), B, Cc, n, D, _stream()), "dcv_ortho_fwd")
+    lib = load()
+    if _deterministic:
+        ws = _workspace(_ws_size(lib.dcv_ortho_fwd_det_ws_floats(B, Cc, n, D)), Y)
+        rc = lib.dcv_ortho_fwd_det(_p(Y), _p(S), _p(selfsq), _p(tot), _p(inv_norm), _p(stats), B, Cc, n, D, _p(ws), ws.numel(), _stream())
+    else:
+        rc = lib.dcv_ortho_fwd(_p(Y), _p(S), _p(selfsq), _p(tot), _p(inv_norm), _p(stats), B, Cc, n, D, _stream())
+    _check(rc, "dcv_ortho_fwd")
 
 
 def ortho_bwd(Y, S, tot, inv_norm, coef, dY, B, Cc, n, D):
@@ -296,7 +360,13 @@ def cast_transpose_bf16(src_base, dst_base, desc_dev, n_desc, max_tiles):
 
 
 def sumsq_acc(x, n, acc):
-    _check(load().dcv_sumsq_acc(_p(x), n, _p(acc), _stream()), "dcv_sumsq_acc")
+    lib = load()
+    if _deterministic:
+        ws = _workspace(_ws_size(lib.dcv_sumsq_det_ws_floats(n)), x)
+        rc = lib.dcv_sumsq_acc_det(_p(x), n, _p(acc), _p(ws), ws.numel(), _stream())
+    else:
+        rc = lib.dcv_sumsq_acc(_p(x), n, _p(acc), _stream())
+    _check(rc, "dcv_sumsq_acc")
 
 
 def clip_scale(x, n, sumsq_dev, max_norm):

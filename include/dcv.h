@@ -82,6 +82,23 @@ int dcv_ln_bwd(const void* du, int du_is_f32, const float* x, long x_row_stride,
                const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
                float* dbeta, int M, int D, void* stream);
 
+/* DETERMINISTIC forms of the other entries that combine partial sums of several workgroups (LayerNorm's dgamma / dbeta, the tokeniser's
+ * d(channel_embed) / d(pos), the diversity loss' per-channel sums, the gradient norm): partials go through `ws` (at least *_det_ws_floats
+ * floats, 16-byte aligned, contents irrelevant) and are added in a fixed order by a second launch.  Same arguments and results otherwise.
+ * With dcv_gemm_tn_acc_det these make a whole training step bit-reproducible (attention, the NT GEMMs and AdamW never were order-dependent). */
+long dcv_ln_bwd_det_ws_floats(int M, int D);
+int dcv_ln_bwd_det(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
+                   const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
+                   float* dbeta, int M, int D, float* ws, long ws_floats, void* stream);
+long dcv_patch_bwd_det_ws_floats(int B, int C, int n, int D);
+int dcv_patch_bwd_det(const float* dx0, const float* dYloss, void* dY_bf16, float* dE, float* dpos, float* dcls, int B, int C, int n,
+                      int D, float* ws, long ws_floats, void* stream);
+long dcv_ortho_fwd_det_ws_floats(int B, int C, int n, int D);
+int dcv_ortho_fwd_det(const float* Y, float* S, float* selfsq, float* tot, float* inv_norm, float* stats, int B, int C, int n, int D,
+                      float* ws, long ws_floats, void* stream);
+long dcv_sumsq_det_ws_floats(long n);
+int dcv_sumsq_acc_det(const float* x, long n, float* acc, float* ws, long ws_floats, void* stream);
+
 /* softmax(q k^T * scale) v for packed qkv [B,N,3,H,64] bf16 -> o [B,N,H*64] bf16, lse [B,H,N] f32.
  * Replaces Attention.forward's q@k^T / softmax / @v (vit.py:123-141); the [B,H,N,N] matrix is never stored. */
 int dcv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale, void* stream);

@@ -470,6 +470,13 @@ def case_base64(dichavit, loss_fn):
     save("base64_fwd", dict(cfg=cfg, mapper=mapper, n_channels=64, img=224, num_classes=161, B=1, seed=111), dict(logits=out.numpy()))
 
 
+def case_base32_train(dichavit, loss_fn):
+    """BASELINE config 5's architecture (DiChaViT-Base, D = 768, 12 heads) as a TRAIN step: 32 channels, 224^2 -> N = 6 273 tokens, batch 1 —
+    the largest channel count whose saved attention matrices (12 x 6273^2 fp32 = 1.9 GB per layer, 23 GB for the twelve) fit this container's
+    62 GB next to the backward's transients.  Logits, losses and every parameter gradient (norm + samples), as in jumpcp_s_b16."""
+    _train_case(dichavit, "base32_train", base_cfg(pretrained_model_name="base"), {"train": list(range(32))}, "train", 32, 32, 224, 161, 1, 131, stages=False)
+
+
 def case_resolution_quirk(dichavit, loss_fn):
     """interpolate_pos_encoding's early-out (dichavit.py:529-530) hit with SEVERAL channels: a 32-px / P8 model (16 grid
     positions) fed 16-px images with 4 channels has 4 x 4 = 16 patch tokens = the model's own count, and H == W: the raw
@@ -566,7 +573,7 @@ def case_init_stats(dichavit, loss_fn):
 CASES = dict(tokendrop=case_tokendrop, resolution=case_resolution, schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
              chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, resume=case_resume,
              chammi_hcs=case_chammi_hcs, jumpcp_b16=case_jumpcp_b16, base64=case_base64, resolution_quirk=case_resolution_quirk,
-             hcs_proj=case_hcs_proj, init_stats=case_init_stats)
+             hcs_proj=case_hcs_proj, init_stats=case_init_stats, base32_train=case_base32_train)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

@@ -169,11 +169,11 @@ def _check_gemm_tn(hip, M, P, Q, **kw):
 
 
 @pytest.mark.parametrize("M,P,Q", [(1000, 384, 384), (4100, 1152, 384), (333, 384, 1536), (64, 128, 128), (5000, 192, 64), (700, 384, 256)])
-def test_gemm_tn(hip, M, P, Q):
+def test_gemm_tn(hip, M, P, Q, reduction_mode):
     _check_gemm_tn(hip, M, P, Q)
 
 
-def test_gemm_tn_random_shapes(hip):
+def test_gemm_tn_random_shapes(hip, reduction_mode):
     """Seeded random weight-gradient problems on both kernels: any reduction length (one row .. several thousand: ragged last stage,
     fewer stages than splits), P / Q multiples of 8 on the 128 x 128 kernel (partial tiles), multiples of 384 / 128 on the wide one."""
     rng = np.random.RandomState(7)
@@ -190,7 +190,7 @@ def test_gemm_tn_random_shapes(hip):
 
 @pytest.mark.parametrize("tile", ["narrow", "wide"])
 @pytest.mark.parametrize("P,Q", [(1152, 384), (384, 384), (1536, 384), (384, 1536), (384, 256)])
-def test_gemm_tn_headline_rows(hip, P, Q, tile):
+def test_gemm_tn_headline_rows(hip, P, Q, tile, reduction_mode):
     """The weight-gradient products of the headline step (reduction over 100 416 token rows split over one resident round of
     workgroups, fp32 atomics), both tile shapes; the last shape is the tokeniser's (P^2 = 256 inputs)."""
     _check_gemm_tn(hip, HEADLINE_M, P, Q, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE)
@@ -225,7 +225,7 @@ def test_gemm_tn_wide_ragged_reduction(hip, M):
 
 
 @pytest.mark.parametrize("M,D", [(1000, 384), (37, 192), (513, 768)])
-def test_layernorm(hip, M, D):
+def test_layernorm(hip, M, D, reduction_mode):
     x = _f(M, D, scale=2.0, seed=1) + 0.5
     g, b = 1 + 0.1 * _f(D, seed=2), 0.1 * _f(D, seed=3)
     u = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
@@ -324,7 +324,7 @@ def test_im2col(hip):
 
 
 @pytest.mark.parametrize("B,C,n,D", [(3, 5, 16, 384), (2, 1, 9, 192), (4, 8, 49, 768)])
-def test_patch_bwd(hip, B, C, n, D):
+def test_patch_bwd(hip, B, C, n, D, reduction_mode):
     T = C * n
     dx0, dYl = _f(B, T + 1, D, seed=1), _f(B, T, D, seed=2)
     dYb = torch.empty(B * T, D, dtype=torch.bfloat16, device="cuda")
@@ -340,8 +340,46 @@ def test_patch_bwd(hip, B, C, n, D):
     _close(dYb.reshape(B, T, D), tok, 1e-2, 1e-2, "dY no loss")
 
 
+def test_deterministic_small_reductions_repeat_bitwise(hip):
+    """LayerNorm's dgamma / dbeta, the tokeniser's d(channel_embed) / d(pos) / d(cls), the diversity statistics and the gradient norm in
+    deterministic mode: three runs on the same inputs are bit-identical (workspace scrambled in between)."""
+    old = hip.set_deterministic(True)
+    try:
+        M, D = 9001, 384
+        x, du, dx_in = _f(M, D, seed=1), _bf(M, D, seed=2), _f(M, D, seed=3)
+        g, b = 1 + 0.1 * _f(D, seed=4), 0.1 * _f(D, seed=5)
+        u = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+        mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+        hip.ln_fwd(x, g, b, u, mean, rstd, M, D, 1e-6)
+        B, C, n = 16, 8, 196
+        dx0 = _f(B, C * n + 1, D, seed=6)
+        Y = _f(B * C * n, D, seed=7)
+        runs = []
+        for rep in range(3):
+            for ws in hip._det_ws.values():
+                ws.uniform_(-1e6, 1e6)
+            dx, dxb = torch.empty(M, D, device="cuda"), torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+            dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+            hip.ln_bwd(du, x, mean, rstd, g, dx_in, dx, dxb, dg, db, M, D)
+            dYb = torch.empty(B * C * n, D, dtype=torch.bfloat16, device="cuda")
+            dE, dpos, dcls = torch.zeros(C, D, device="cuda"), torch.zeros(n + 1, D, device="cuda"), torch.zeros(D, device="cuda")
+            hip.patch_bwd(dx0, None, dYb, dE, dpos, dcls, B, C, n, D)
+            S, ssq = torch.empty(B, C, D, device="cuda"), torch.empty(B, C, device="cuda")
+            tot, inv, stats = torch.empty(B, D, device="cuda"), torch.empty(B, C * n, device="cuda"), torch.empty(B, 2, device="cuda")
+            hip.ortho_fwd(Y, S, ssq, tot, inv, stats, B, C, n, D)
+            acc = torch.zeros(1, device="cuda")
+            hip.sumsq_acc(x, x.numel(), acc)
+            runs.append([t.clone() for t in (dg, db, dx, dE, dpos, dcls, S, ssq, stats, acc)])
+        for r in runs[1:]:
+            for a, c in zip(runs[0], r):
+                assert torch.equal(a, c)
+        assert abs(runs[0][-1].item() - x.double().pow(2).sum().item()) <= 1e-5 * x.numel()
+    finally:
+        hip.set_deterministic(old)
+
+
 @pytest.mark.parametrize("B,C,n,D", [(3, 5, 16, 384), (2, 1, 9, 192), (2, 8, 196, 384), (2, 18, 16, 384)])
-def test_ortho_loss(hip, B, C, n, D):
+def test_ortho_loss(hip, B, C, n, D, reduction_mode):
     from oracle import dichavit_oracle as orc
     T = C * n
     Y = _f(B, T, D, seed=3) + 0.3

@@ -261,17 +261,18 @@ def test_loss_curve_100_steps(gpu_device):
     contribute: they are stochastically rounded every step (include/dcv.h dcv_cast_bf16_sr).  With round-to-nearest
     copies (second run below) Adam's +-lr = 4.9e-5 sign steps are lost below the bf16 ulp, the copies lag the fp32
     master coherently, and the curve is 10x further off (max 6e-2, mean 6e-3) — kept as a regression contrast.
-    Asserted (stochastic, default) at <= 1.5 x the worst of the values measured on MI355X, so that a regression shows.  The
-    trajectory is not reproducible run to run (the fp32 atomic adds of the weight-gradient GEMMs land in a different order every
-    launch, and the early curve amplifies that): 11 runs of the final round-2 build gave step0 8.6e-5, max 5.0e-3 .. 1.07e-2,
-    mean 4.1e-4 .. 7.2e-4, tail 5.7e-5 .. 9.4e-5 (earlier builds: step0 up to 9.4e-4).  Bounds: step0 <= 1.5e-3, max <= 1.6e-2,
-    mean <= 1.1e-3, last 20 steps <= 2e-4."""
+    Asserted at 1.2 x ONE reproducible value (round 3): the tests run in deterministic mode (diverse_channel_vit_amd.set_deterministic —
+    weight gradients and every other cross-workgroup sum in a fixed order), so the trajectory is bit-identical from run to run on a given
+    build (two processes printed the same digits: step0 1.06e-3, max 5.221e-3, mean 4.962e-4, last 20 steps 9.199e-5; round-to-nearest
+    copies: 4.02e-4 / 6.332e-2 / 6.126e-3 / 3.619e-4; a second deterministic build with another association order in LayerNorm's
+    dgamma sums: 1.06e-3 / 4.575e-3 / 4.894e-4 / 9.650e-5 — this curve is well conditioned, unlike the batch-2 one below).  With fp32 atomics
+    (round 2) eleven runs of one build spread over max 5.0e-3 .. 1.07e-2.  Bounds = 1.2 x the larger of the two deterministic builds."""
     e_sr, ref = _run_curve(gpu_device, "curve100_so2sat_s", True)
     e_rn, _ = _run_curve(gpu_device, "curve100_so2sat_s", False)
     _curve_report("loss-curve so2sat-s stochastic", e_sr, ref)
     _curve_report("loss-curve so2sat-s nearest   ", e_rn, ref)
-    assert e_sr[0] <= 1.5e-3 and e_sr.max() <= 1.6e-2 and e_sr.mean() <= 1.1e-3 and e_sr[-20:].max() <= 2e-4
-    assert e_rn[0] <= 1e-3 and e_rn.max() <= 8.5e-2 and e_rn.mean() <= 8.5e-3 and e_rn[-20:].max() <= 1e-3
+    assert e_sr[0] <= 1.3e-3 and e_sr.max() <= 6.3e-3 and e_sr.mean() <= 6.0e-4 and e_sr[-20:].max() <= 1.2e-4
+    assert e_rn[0] <= 4.9e-4 and e_rn.max() <= 7.6e-2 and e_rn.mean() <= 7.4e-3 and e_rn[-20:].max() <= 4.4e-4
     assert e_sr.mean() < 0.5 * e_rn.mean()
 
 
@@ -281,10 +282,14 @@ def test_loss_curve_headline_architecture(gpu_device):
     steps move by up to 0.3), so the trajectory is sensitive: two builds whose kernels differ in the last bf16 bit measured
     stochastic max 2.8e-2 / mean 1.8e-3 / tail 9e-4 and max 6.6e-2 / mean 4.1e-3 / tail 2.2e-3; round-to-nearest copies
     max 1.2e-1..1.5e-1 / mean 1.0e-2..1.4e-2 / tail 5e-3..7e-3 on the same builds.
-    Run to run on ONE build the spread is as wide (atomic-add order, see above): 11 runs of the final round-2 build gave max
-    1.6e-2 .. 6.0e-2, mean 1.5e-3 .. 3.8e-3, tail 7.7e-4 .. 2.6e-3.
-    Asserted (stochastic, default) at 1.5 x the worst value seen: step0 <= 2.1e-3, max <= 0.1, mean <= 6.2e-3, tail <= 3.9e-3;
-    round-to-nearest (contrast only): max <= 0.23, mean <= 2.1e-2."""
+    With fp32 atomics (round 2) eleven runs of one build spread over max 1.6e-2 .. 6.0e-2, mean 1.5e-3 .. 3.8e-3, tail 7.7e-4 .. 2.6e-3.
+    In deterministic mode (round 3, the default) a build is bit-reproducible run to run — but this batch-2 run is chaotic, not just noisy:
+    two deterministic builds that differ ONLY in the association order of LayerNorm's dgamma / dbeta partial sums (16 interleaved lanes
+    instead of one sequential walk over the 1024 partials) printed step0 1.01e-3 / max 1.460e-2 / mean 1.534e-3 / tail 8.703e-4 and
+    step0 1.01e-3 / max 3.328e-2 / mean 2.730e-3 / tail 1.759e-3 — both inside the envelope the atomic runs had drawn.  A bound at
+    1.2 x one such value would test the summation order, not the arithmetic; the well-conditioned So2Sat curve above carries the tight
+    bound, this one keeps the envelope of all equally correct orders seen so far x 1.5: step0 <= 2.1e-3 (it does not depend on the
+    order: no update has happened yet), max <= 0.1, mean <= 6.2e-3, tail <= 3.9e-3; round-to-nearest (contrast only): max <= 0.23, mean <= 2.1e-2."""
     e_sr, ref = _run_curve(gpu_device, "curve100_jumpcp_s", True)
     e_rn, _ = _run_curve(gpu_device, "curve100_jumpcp_s", False)
     _curve_report("loss-curve headline stochastic", e_sr, ref)
@@ -343,7 +348,13 @@ def test_graphed_step_matches_eager(gpu_device, rounding):
     # noise can flip single roundings too.
     d = (we - wg).abs()
     print(f"graph vs eager ({rounding}): max |dW| {d.max().item():.2e}, mean {d.mean().item():.2e}")
-    assert d.max().item() <= 1e-3 and d.mean().item() <= (5e-6 if rounding == "nearest" else 2e-5), (d.max().item(), d.mean().item())
+    # round 3: the tests run in deterministic mode, where the replayed graph and the eager launches execute the same sums in the same
+    # order — the weights after six steps are BIT-identical (the bounds above are what the fp32-atomic mode needs)
+    import diverse_channel_vit_amd as dcv_
+    if dcv_.is_deterministic():
+        assert torch.equal(we, wg) and le[2:] == lg
+    else:
+        assert d.max().item() <= 1e-3 and d.mean().item() <= (5e-6 if rounding == "nearest" else 2e-5), (d.max().item(), d.mean().item())
     assert runs["eager"][3] == runs["graph"][3] == (None if rounding == "nearest" else 7)
     assert lg[-1] < lg[0]
 
@@ -661,6 +672,52 @@ def test_headline_batch16_multi_round_gemm_parity(gpu_device):
     _golden_grad_check(model, a)
 
 
+def test_base_32_channels_6273_tokens_train_step(gpu_device):
+    """BASELINE config 5's architecture as a TRAIN step: DiChaViT-Base (D = 768, 12 heads), 32 channels x 196
+    patches + CLS = 6 273 tokens, batch 1, against the real reference (tests/golden/base32_train.npz — the largest channel count whose
+    saved fp32 attention matrices fit the build container): logits, losses and every parameter gradient's norm and samples.  The
+    whole-model backward at a long sequence: attention dQ / dK / dV over 49 key tiles x 49 query tiles per head, GEMMs with K = 768 / 3072."""
+    meta, a = load_golden("base32_train")
+    model, _ = build(meta, gpu_device)
+    model.stochastic_weight_rounding = False
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], 32, 224, 161)
+    out, extra = model(x.to(gpu_device), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    loss = torch.nn.CrossEntropyLoss()(out, y.to(gpu_device)) + extra
+    loss.backward()
+    lg = a["logits"]
+    err = np.abs(out.detach().cpu().numpy() - lg).max()
+    print(f"base/32ch/N=6273 train step: max |dlogit| {err:.3e} (max |logit| {np.abs(lg).max():.3f}) loss {loss.item():.6f} (reference {float(a['loss']):.6f})")
+    assert err <= 3e-2 * np.abs(lg).max()
+    assert abs(extra.item() - float(a["extra"])) <= 2e-2 * abs(float(a["extra"])) + 1e-6
+    assert abs(loss.item() - float(a["loss"])) <= 1.2e-2  # Base width: sqrt(2) per GEMM and per residual width over DiChaViT-S's 5e-3 (test_base_width_train_step)
+    _golden_grad_check(model, a)
+
+
+def test_deterministic_mode_train_step_is_bit_reproducible(gpu_device):
+    """with diverse_channel_vit_amd.set_deterministic(True) (the tests' default; the reference sets
+    cudnn.deterministic = True, utils.py:394-401) two runs of the headline architecture's train step at batch 16 — weight gradients split
+    over ~250 workgroups per product, second stream on — give bit-identical logits, loss and gradients for every parameter, with
+    stochastically rounded weight copies (same seed) as in training."""
+    import diverse_channel_vit_amd as dcv
+    assert dcv.is_deterministic()
+    meta, a = load_golden("jumpcp_s_b16")
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], 8, 224, 161)
+    x, y = x.to(gpu_device), y.to(gpu_device)
+    runs = []
+    for rep in range(2):
+        model, _ = build(meta, gpu_device)
+        out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+        loss.backward()
+        torch.cuda.synchronize()
+        runs.append((out.detach().clone(), loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        del model
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][2].keys() == runs[1][2].keys() and len(runs[0][2]) > 100
+    diff = [n for n in runs[0][2] if not torch.equal(runs[0][2][n], runs[1][2][n])]
+    assert not diff, f"{len(diff)} gradient tensors differ between two deterministic runs, e.g. {diff[:3]}"
+
+
 def test_chammi_hcs_nonidentity_mapper_parity(gpu_device):
     """BASELINE config 3 as specified: CHAMMI 12-channel model with enable_sample=True.  The subsets the reference drew are
     pinned through hcs_sampler; on HPA / CP the sampled GLOBAL ids (rows of channel_embed / channel_emb_proxies) differ from
@@ -683,9 +740,23 @@ def test_chammi_hcs_nonidentity_mapper_parity(gpu_device):
             ref = a[f"d{k}_feat"]
             assert np.abs(feat.detach().cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max(), d
             assert abs(extra.item() - float(a[f"d{k}_extra"])) <= 2e-2 * abs(float(a[f"d{k}_extra"])) + 1e-6
-            # the proxy logits multiply the feature error by 1/temperature = 14 (test_chammi_chunks_parity); on the sampled
-            # 1-2 channel subsets the CLS feature averages over fewer tokens: measured up to 1.3e-2 (0.4 % of the loss)
-            assert abs(loss.item() - float(a[f"d{k}_loss"])) <= 2e-2, (d, loss.item(), float(a[f"d{k}_loss"]))
+            # Derived tolerance, not "measured plus margin".  proxy_loss (loss_fn.py:7-21) is cross-entropy over the
+            # logits -|s f^ - s p^_k|^2 = 2 s^2 cos(f, p_k) + const with s^2 = 1/temperature = 14.29 and f^, p^ unit vectors, so
+            # g = d loss / d f^ = 2 s^2 sum_k (softmax_k - y_k) p^_k with |g| <= 2 s^2 sqrt(2) = 40.4 (|softmax - y|_2 <= sqrt 2).
+            #   worst case:  |d loss| <= 40.4 e,  e = batch mean of |f^_hip - f^_ref|, the error of the NORMALISED feature;
+            #   expected:    the bf16 rounding error of f^ has no preferred direction among the D = 384 coordinates while g is one
+            #                fixed direction, so d loss = <g, df^> has standard deviation 40.4 e / sqrt(D) = 2.06 e: asserted at 3 sigma.
+            # e itself is bounded at 8e-3 (measured 2e-3 .. 5.7e-3: largest on the 1-channel draws, whose 197-token sequences
+            # average the rounding of fewer tokens into the CLS feature) — that bound is what a regression in the kernels would break.
+            fh = torch.nn.functional.normalize(feat.detach().double().cpu(), dim=-1)
+            fr = torch.nn.functional.normalize(torch.from_numpy(ref).double(), dim=-1)
+            e = (fh - fr).norm(dim=-1).mean().item()
+            dl = abs(loss.item() - float(a[f"d{k}_loss"]) - (extra.item() - float(a[f"d{k}_extra"])))
+            gmax = 2 * math.sqrt(2) / meta["cfg"]["temperature"]
+            print(f"chammi-hcs draw {k} ({d['chunk']}, {len(picked)} ch): normalised-feature error {e:.3e}  |d main loss| {dl:.3e}  "
+                  f"3 sigma {3 * gmax * e / math.sqrt(fh.shape[-1]):.3e}  worst case {gmax * e:.3e}")
+            assert e <= 8e-3, (d, e)
+            assert dl <= 3 * gmax * e / math.sqrt(fh.shape[-1]) + 1e-5, (d, dl, e)
             k += 1
         assert sorted(model.feature_extractor.patch_embed.counter.keys()) == sorted({c for j in range(3 * rnd, 3 * rnd + 3) for c in a[f"d{j}_picked"].tolist()})
         _golden_grad_check(model, a, prefix=f"r{rnd}/")
