@@ -866,6 +866,7 @@ struct GemmTnArgs {
     int m_per_split, splits;
     float* part;       // deterministic mode: split s stores its partial tile to part[s * part_stride + p * Q + q] (and its bias partial to
     long part_stride;  // part[s * part_stride + P * Q + p]) with plain stores instead of adding atomically; det_reduce_kernel sums them
+    long bias_off;     // gemm_tn384, deterministic mode: float offset in `part` of the bias partials [splits * tiles_q][P]
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
@@ -1090,8 +1091,11 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
         return base + lds128_off(row, col);
     };
 
-    // bias gradient: workgroups of the first Q tile add up their Y images (48 column chunks x 10 row groups)
-    const bool do_bias = (a.dbias != nullptr) && (tq == 0);
+    // bias gradient: the workgroups add up their Y images (48 column chunks x 10 row groups) — every workgroup of a row of tiles for the
+    // stages kt % tiles_q == tq, so that the tiles of a split keep the same pace.  With the tq == 0 tiles doing all of it (rounds 1-2) they fell
+    // behind, the tiles of a split drifted apart and the shared operand rows left L2 before the slower tiles read them: 675 MB from HBM per
+    // launch at P = 1536, Q = 384 against 425 MB now (386 MB = the operands once); the launch 175 -> 160 us (profiles/r03_x7_*)
+    const bool do_bias = (a.dbias != nullptr);
     const int bch = tid % 48, brg = tid / 48;  // threads >= 480 idle for this
     float bs[8];
 #pragma unroll
@@ -1131,7 +1135,7 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
 #else
         asm volatile("" ::"v"(st));
 #endif
-        if (do_bias && brg < 10) {
+        if (do_bias && (kt % tiles_q) == tq && brg < 10) {
             const int im = bch >> 4, ci = bch & 15;
             for (int r = brg; r < T3_BK; r += 10) {
                 const int pc = ((((ci >> 2) ^ (r & 3)) << 2) | (ci & 3));
@@ -1175,7 +1179,7 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
             float sum = 0.f;
 #pragma unroll
             for (int g = 0; g < 10; ++g) sum += red[g * 384 + tid];
-            if (a.part) a.part[(size_t)split * a.part_stride + (size_t)a.P * a.Q + p0 + tid] = sum;
+            if (a.part) a.part[a.bias_off + ((size_t)split * tiles_q + tq) * a.P + p0 + tid] = sum;  // one row per (split, tq)
             else atomicAdd(a.dbias + p0 + tid, sum);
         }
     }
@@ -1313,7 +1317,7 @@ static void tn_plan(int M, int P, int Q, int pick, int cus, int& splits, int& mp
         if (splits < 1) splits = 1;
         mps = ((M + splits - 1) / splits + BK - 1) / BK * BK;
     }
-    splits = (M + mps - 1) / mps;  // every split has rows
+    splits = (M + mps - 1) / mps;  // the splits that have rows (the leading ones)
 }
 
 static int tn_launch(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias, int tile,
@@ -1329,12 +1333,18 @@ static int tn_launch(const void* Y, int ldy, const void* X, int ldx, int M, int 
     if (pick < 0) return pick;
     int splits, mps;
     tn_plan(M, P, Q, pick, cus, splits, mps);
-    const long stride = (long)P * Q + P;
+    // deterministic workspace: narrow kernel [splits][P*Q + P] (partial tile, then its bias partial); gemm_tn384, whose every tile
+    // contributes to the bias gradient: [splits][P*Q], then [splits * tiles_q][P]
+    const bool sep = pick != DCV_TILE_NARROW;
+    const int tq9 = Q / 128;
+    const long stride = sep ? (long)P * Q : (long)P * Q + P;
+    const long bias_off = stride * splits;
+    const long need = sep ? bias_off + (long)splits * tq9 * P : stride * splits;
     if (ws) {
         if (((uintptr_t)ws & 15) || (lddw % 4) || ((uintptr_t)dW & 15) || (dbias && ((uintptr_t)dbias & 15))) return DCV_ERR_ALIGN;
-        if (ws_floats < stride * splits) return DCV_ERR_SHAPE;
+        if (ws_floats < need) return DCV_ERR_SHAPE;
     }
-    GemmTnArgs a{(const bf16_t*)Y, ldy, (const bf16_t*)X, ldx, M, P, Q, dW, lddw, dbias, mps, splits, ws, stride};
+    GemmTnArgs a{(const bf16_t*)Y, ldy, (const bf16_t*)X, ldx, M, P, Q, dW, lddw, dbias, mps, splits, ws, stride, bias_off};
     if (pick == DCV_TILE_WIDE) {
         hipLaunchKernelGGL(gemm_tn384_kernel, dim3((P / 384) * (Q / 128) * splits), dim3(512), 0, (hipStream_t)stream, a);
     } else {
@@ -1342,7 +1352,12 @@ static int tn_launch(const void* Y, int ldy, const void* X, int ldx, int M, int 
     }
     DCV_LAUNCH_CHECK();
     if (ws) {
-        if (!det_reduce(ws, splits, stride, dW, (long)P * Q, Q, lddw, dbias, dbias ? P : 0, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
+        if (sep) {
+            if (!det_reduce(ws, splits, stride, dW, (long)P * Q, Q, lddw, nullptr, 0, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
+            if (dbias && !det_reduce(ws + bias_off, splits * tq9, P, dbias, P, P, P, nullptr, 0, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
+        } else if (!det_reduce(ws, splits, stride, dW, (long)P * Q, Q, lddw, dbias, dbias ? P : 0, (hipStream_t)stream)) {
+            return DCV_ERR_LAUNCH;
+        }
     }
     return DCV_OK;
 }
@@ -1358,7 +1373,8 @@ extern "C" long dcv_gemm_tn_det_ws_floats(int M, int P, int Q, int tile) {
     if (pick < 0) return pick;
     int splits, mps;
     tn_plan(M, P, Q, pick, dcv_cu_count(), splits, mps);
-    return ((long)P * Q + P) * splits;
+    if (pick == DCV_TILE_NARROW) return ((long)P * Q + P) * splits;
+    return (long)splits * P * Q + (long)splits * (Q / 128) * P;
 }
 
 extern "C" int dcv_gemm_tn_acc_det(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,

@@ -188,12 +188,15 @@ def test_gemm_tn_random_shapes(hip, reduction_mode):
             raise AssertionError(f"M={M} P={P} Q={Q} wide={wide}: {e}") from e
 
 
+_TN_TILES = {"narrow": 1, "wide": 2}  # hip.TILE_*
+
+
 @pytest.mark.parametrize("tile", ["narrow", "wide"])
 @pytest.mark.parametrize("P,Q", [(1152, 384), (384, 384), (1536, 384), (384, 1536), (384, 256)])
 def test_gemm_tn_headline_rows(hip, P, Q, tile, reduction_mode):
     """The weight-gradient products of the headline step (reduction over 100 416 token rows split over one resident round of
-    workgroups, fp32 atomics), both tile shapes; the last shape is the tokeniser's (P^2 = 256 inputs)."""
-    _check_gemm_tn(hip, HEADLINE_M, P, Q, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE)
+    workgroups), both tile shapes, atomic and deterministic; the last shape is the tokeniser's (P^2 = 256 inputs)."""
+    _check_gemm_tn(hip, HEADLINE_M, P, Q, tile=_TN_TILES[tile])
 
 
 @pytest.mark.parametrize("tile", ["narrow", "wide"])
@@ -202,7 +205,7 @@ def test_gemm_tn_deterministic(hip, M, P, Q, tile):
     """dcv_gemm_tn_acc_det (the reference runs with cudnn.deterministic, utils.py:394-401): the splits store their
     partial tiles to a workspace and a second launch adds them in a fixed order.  Same value as the reference product, bit-identical
     from run to run (the atomic form is not), and the workspace may hold anything beforehand."""
-    t = hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE
+    t = _TN_TILES[tile]
     nws = hip.gemm_tn_det_ws_floats(M, P, Q, t)
     ws = torch.full((nws,), float("nan"), device="cuda")  # poisoned: every element the reducer reads must have been written
     _check_gemm_tn(hip, M, P, Q, tile=t, ws=ws)

@@ -378,25 +378,30 @@ def test_dp_reducer_on_rccl_single_gpu(gpu_device):
         x, y = orc.make_batch(5, 4, 18, 32, 17)
         x, y = x.to(gpu_device), y.to(gpu_device)
         grads = {}
-        for mode in ("plain", "dp"):
+        # also the bf16 exchange and the no-overlap (one collective after the backward) flags on the RCCL backend
+        for mode in ("plain", "dp", "dp_bf16", "dp_no_overlap"):
             model, _ = build(meta, gpu_device)
-            if mode == "dp":
+            if mode != "plain":
                 model._ensure_arena(gpu_device)
-                dp = dcv.DataParallel(model, min_bucket_bytes=1 << 20, force_collectives=True)
+                dp = dcv.DataParallel(model, min_bucket_bytes=1 << 20, force_collectives=True,
+                                      grad_dtype=torch.bfloat16 if mode == "dp_bf16" else torch.float32, overlap=mode != "dp_no_overlap")
                 dp.broadcast_parameters(0)
                 dp.hook_misc_params()
             opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, model=model)
             opt.zero_grad()
             out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
             (torch.nn.functional.cross_entropy(out, y) + extra).backward()
-            if mode == "dp":
-                assert dp.buckets_launched >= 8  # 12 blocks (7 MB each) merged/kept + tokeniser + final norm + misc params
+            if mode != "plain":
+                # 12 blocks (7 MB each) merged/kept + tokeniser + final norm + misc params; no overlap: ONE collective of everything
+                assert dp.buckets_launched >= (8 if mode != "dp_no_overlap" else 1)
                 dp.finalize()
             grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
             opt.step()
-        for k, g in grads["plain"].items():
-            ref = g.abs().max().item()
-            assert (grads["dp"][k] - g).abs().max().item() <= 1e-3 * ref + 1e-9, k
+        for mode in ("dp", "dp_bf16", "dp_no_overlap"):
+            for k, g in grads["plain"].items():
+                ref = g.abs().max().item()
+                # bf16 exchange: every element rounded to bf16 once (2^-9 relative)
+                assert (grads[mode][k] - g).abs().max().item() <= (4e-3 if mode == "dp_bf16" else 1e-3) * ref + 1e-9, (mode, k)
         # and against the checker: every gradient that went through RCCL vs the fp64 oracle on the same batch
         ch = meta["mapper"][meta["chunk"]]
         sd_ref, *_ = oracle_grads(meta, x.cpu(), y.cpu(), ch, list(range(len(ch))))
@@ -930,15 +935,21 @@ def test_graph_replays_without_host_sync_follow_eager(gpu_device):
     assert diff.max().item() <= 1.5e-3 and diff.mean().item() <= 2e-5, (diff.max().item(), diff.mean().item())
 
 
-def _two_rank_worker(rank, world, port, q, grad_dtype, overlap):
+def _two_rank_worker(rank, world, port, q, grad_dtype, overlap, backend="gloo"):
     import os
     import sys
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # gloo: both ranks on cuda:0 (RCCL refuses two ranks on one device); nccl (= RCCL): one GPU per rank, real asynchronous collectives
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import diverse_channel_vit_amd as dcv
-        dev = torch.device("cuda:0")
         meta, _ = load_golden("tiny_e2e")
         ce = torch.nn.CrossEntropyLoss()
         batches = {(r, k): orc.make_batch(500 + 10 * r + k, 2, 3, 32, 5) for r in range(world) for k in range(2)}
@@ -1011,6 +1022,45 @@ def test_dp_two_ranks_real_model_two_backwards(gpu_device, grad_dtype, overlap):
             print(f"two ranks, two backward passes: worst relative gradient difference vs single-process sum {worst:.2e}")
             # fp32 exchange: the atomic ordering noise of the weight-gradient GEMMs only; bf16 exchange: every bucket element rounded to bf16
             # once per pass (2^-9 relative per element)
+            assert worst <= (2e-3 if grad_dtype == "float32" else 8e-3), worst
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("grad_dtype,overlap", [("float32", True), ("bfloat16", True), ("float32", False)])
+def test_dp_two_ranks_rccl_two_gpus(gpu_device, grad_dtype, overlap):
+    """the same two-rank check over REAL RCCL — one GPU per rank, asynchronous all-reduces issued from the
+    weight-gradient stream while the backward continues, the autograd-engine end-of-backward callback as the only synchronisation.
+    Needs two visible GPUs: skipped on the one-GPU test boxes (no run on more than one GPU exists yet: DESIGN.md section 5), runs
+    wherever `pytest -m gpu` sees a multi-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q, grad_dtype, overlap, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue as _q
+    import time as _t
+    res, t0 = [], _t.time()
+    while len(res) < 2:
+        try:
+            res.append(q.get(timeout=2))
+        except _q.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or _t.time() - t0 > 500:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail(f"a rank exited with {dead} (or timed out)")
+    for p in procs:
+        p.join(60)
+    for rank, worst, nb, nh in res:
+        assert nb >= (2 if overlap else 1) and nh <= 8
+        if rank == 0:
+            print(f"two ranks over RCCL: worst relative gradient difference vs single-process sum {worst:.2e}")
             assert worst <= (2e-3 if grad_dtype == "float32" else 8e-3), worst
 
 
