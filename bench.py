@@ -406,6 +406,20 @@ def main():
             if r["symbol"] in pmc:
                 v = pmc[r["symbol"]]
                 r["pmc_mbytes_per_launch"] = round((v["read_bytes_per_launch"] + v["written_bytes_per_launch"]) / 1e6, 1)
+        # matrix-pipe utilisation per (symbol, shape) from the committed SQ-counter passes (tools/pmc_gemm.sh at the headline shapes):
+        # mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), the share of wall cycles the MFMA pipes are busy
+        sq_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_gemm_sq_counters.json")),
+                          key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
+        if headline and sq_files:
+            with open(sq_files[-1]) as f:
+                sq = json.load(f)
+            for r in table:
+                v = sq.get(f"{r['symbol']}|{r['shape']}")
+                if v:
+                    r["mfma_busy_frac"] = v["mfma_busy_frac"]
+                    r["valu_mfma_coexec_frac"] = v["valu_mfma_coexec_frac"]
+                    r["lds_bank_conflict_frac"] = round((v.get("lds_bank_conflict_cycles") or 0.0) / max(v.get("lds_active_cycles") or 1.0, 1.0), 4)
+                    r["sq_counter_source"] = "profiles/" + os.path.basename(sq_files[-1])
         exec_gf = TRAIN_GFLOP_PER_IMG - (DEAD_GFLOP_PER_IMG if model.cls_only_tail else 0.0)
         imgs = args.batch * world * args.steps / dt
         imgs_med = args.batch * world / (med_ms * 1e-3)

@@ -263,6 +263,10 @@ template <int EPI>
 __device__ __forceinline__ void epi_store4(const GemmNtArgs& a, int m, int n, const f32x4& acc, const float* x, const float4& bz) {
     float4 v = make_float4(acc[0] + bz.x, acc[1] + bz.y, acc[2] + bz.z, acc[3] + bz.w);
     if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
+        if (a.aux2) {  // stochastic depth (vit.py:37-56, 397-398): the branch of sample b = m / T is multiplied by aux2[b] = keep_b / keep_prob
+            const float sc = a.aux2[m / a.T];
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+        }
         v.x += x[0]; v.y += x[1]; v.z += x[2]; v.w += x[3];
         *reinterpret_cast<float4*>((float*)a.out + (size_t)m * a.ldo + n) = v;
     } else if constexpr (EPI == DCV_EPI_PATCH) {
@@ -1135,7 +1139,10 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
 #else
         asm volatile("" ::"v"(st));
 #endif
-        if (do_bias && (kt % tiles_q) == tq && brg < 10) {
+#ifndef DCV_TN_BIAS_TQ0
+#define DCV_TN_BIAS_TQ0 0  // A/B switch: 1 = the round-2 assignment (the tq == 0 workgroups sum every stage)
+#endif
+        if (do_bias && (DCV_TN_BIAS_TQ0 ? tq == 0 : (kt % tiles_q) == tq) && brg < 10) {
             const int im = bch >> 4, ci = bch & 15;
             for (int r = brg; r < T3_BK; r += 10) {
                 const int pc = ((((ci >> 2) ^ (r & 3)) << 2) | (ci & 3));
@@ -1256,6 +1263,7 @@ extern "C" int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, in
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
     if (grid_cap < 0 || tile < DCV_TILE_AUTO || tile > DCV_TILE_WIDE) return DCV_ERR_SHAPE;
+    if (epilogue == DCV_EPI_BIAS_RESID_F32 && aux2 && (T <= 0 || (M % T) != 0)) return DCV_ERR_SHAPE;  // per-sample branch scale: T rows per sample
     // persistent kernels: one workgroup per CU walks the tiles; grid_cap (> 0) lowers the number of workgroups — the data-parallel
     // backward leaves CUs to RCCL's kernels this way (dichavit.py), tests force multi-round walks on small problems
     const int cap = grid_cap > 0 ? grid_cap : dcv_cu_count();

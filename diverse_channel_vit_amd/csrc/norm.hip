@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du
                                                      const float* __restrict__ gamma, const float* dx_in, float* dx_out,
                                                      bf16_t* __restrict__ dx_bf16, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta, int M, int D, long x_row_stride,
-                                                     long dx_row_stride, float* __restrict__ part) {
+                                                     long dx_row_stride, float* __restrict__ part, const float* __restrict__ bscale,
+                                                     int rows_per_sample) {
     // part != nullptr (deterministic mode): workgroup b stores its column sums to part[b][2][D] instead of adding them atomically
     __shared__ float red[4][2][MAXV * 64 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -175,6 +176,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ du
                 LN_STORE(reinterpret_cast<f32x4*>(dx_out + (size_t)row * dx_row_stride) + c, r);
                 if (dx_bf16) {
                     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    if (bscale) {  // the copy feeds the residual branch below: DropPath's per-sample factor multiplies that branch's gradient
+                        const float sc = bscale[row / rows_per_sample];
+                        r.x *= sc; r.y *= sc; r.z *= sc; r.w *= sc;
+                    }
                     const uint2 pk = pack4_bf16(r.x, r.y, r.z, r.w);
                     LN_STORE(reinterpret_cast<u32x2*>(dx_bf16 + (size_t)row * D) + c, (u32x2{pk.x, pk.y}));
                 }
@@ -249,14 +254,16 @@ static int ln_bwd_grid(int M) {
 }
 static int ln_bwd_launch(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
                          const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
-                         float* dbeta, int M, int D, float* ws, long ws_floats, void* stream) {
+                         float* dbeta, int M, int D, float* ws, long ws_floats, void* stream, const float* bscale = nullptr,
+                         int rows_per_sample = 1) {
     if (!du || !x || !mean || !rstd || !gamma || !dx_out || !dgamma || !dbeta) return DCV_ERR_NULL;
     if (M <= 0 || D <= 0 || (D & 3) || D > 64 * 4 * MAXV_MAX || (x_row_stride & 3) || (dx_row_stride & 3)) return DCV_ERR_SHAPE;
+    if (bscale && (rows_per_sample <= 0 || (M % rows_per_sample) != 0)) return DCV_ERR_SHAPE;
     const int grid = ln_bwd_grid(M);
     if (ws && ws_floats < (long)grid * 2 * D) return DCV_ERR_SHAPE;
 #define DCV_LN_BWD(F32, V)                                                                                                          \
     hipLaunchKernelGGL((ln_bwd_kernel<F32, V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, du, x, mean, rstd, gamma, dx_in, dx_out, \
-                       (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride, ws)
+                       (bf16_t*)dx_bf16, dgamma, dbeta, M, D, x_row_stride, dx_row_stride, ws, bscale, rows_per_sample)
     if (D <= 512) {
         if (du_is_f32) DCV_LN_BWD(true, 2);
         else DCV_LN_BWD(false, 2);
@@ -283,4 +290,12 @@ extern "C" int dcv_ln_bwd_det(const void* du, int du_is_f32, const float* x, lon
     if (!ws) return DCV_ERR_NULL;
     return ln_bwd_launch(du, du_is_f32, x, x_row_stride, mean, rstd, gamma, dx_in, dx_out, dx_row_stride, dx_bf16, dgamma, dbeta, M, D,
                          ws, ws_floats, stream);
+}
+extern "C" int dcv_ln_bwd_scaled(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
+                                 const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
+                                 float* dbeta, int M, int D, const float* bf16_row_scale, int rows_per_sample, float* ws, long ws_floats,
+                                 void* stream) {
+    if (!bf16_row_scale || !dx_bf16) return DCV_ERR_NULL;
+    return ln_bwd_launch(du, du_is_f32, x, x_row_stride, mean, rstd, gamma, dx_in, dx_out, dx_row_stride, dx_bf16, dgamma, dbeta, M, D,
+                         ws, ws_floats, stream, bf16_row_scale, rows_per_sample);
 }

@@ -147,8 +147,7 @@ class PatchEmbedPerChannel(_Holder):
                 nn.init.trunc_normal_(self.channel_embed.weight, std=0.02, a=-2.0, b=2.0)
             if _cfg_get(cfg, "freeze_channel_emb", False):
                 self.channel_embed.weight.requires_grad = False
-        else:
-            raise ValueError("use_channelvit_channels=False is not supported by the HIP path")
+        # use_channelvit_channels=False (dichavit.py:83-95, 121, 409): no channel_embed parameter, tokens carry no channel offset
         self.use_channelvit_channels = use_channelvit_channels
         self.enable_sample = enable_sample
 
@@ -166,8 +165,8 @@ class ChannelVisionTransformer(_Holder):
             raise ValueError(f"Unknown block type: {cfg.block_type}")
         if _cfg_get(cfg, "dropout_tokens_hcs", "none") not in (None, "none", "random", "channel", "channel_random50", "token_random50"):
             raise ValueError(f"Unknown dropout_tokens_hcs: {cfg.dropout_tokens_hcs}")
-        if (_cfg_get(cfg, "drop_path_rate", 0.0) or 0.0) != 0.0:
-            raise ValueError("drop_path_rate > 0 is not supported by the HIP path (all reference scripts use 0)")
+        # stochastic depth (vit.py:37-56, 373, 397-398): per-block rates linspace(0, drop_path_rate, depth) (models/dichavit.py:475)
+        self.drop_path_rates = [float(v) for v in torch.linspace(0, float(_cfg_get(cfg, "drop_path_rate", 0.0) or 0.0), depth)]
         self.num_features = self.embed_dim = self.out_dim = embed_dim
         self.in_chans = in_chans
         self.num_heads = num_heads
@@ -255,6 +254,7 @@ class DiChaViT(nn.Module):
         self._R_cache: Dict = {}
         self._idx_cache: Dict = {}
         self.hcs_sampler = None  # optional callable(model, chunk_name, cur_channels) -> (picked ids, positions): pins the subset
+        self.drop_path_sampler = None  # optional callable(block, "attn" | "mlp", B, device) -> 0/1 keep mask [B]: pins DropPath's draws
         self._in_scale = self._in_shift = None  # optional per-global-channel input affine (set_input_normalisation)
         self._cur_scale = self._cur_shift = None  # the affine rows of the channels used by the current forward
         # bf16 operand copies of the weights: stochastically rounded on training forwards (unbiased w.r.t. the fp32
@@ -537,6 +537,29 @@ class DiChaViT(nn.Module):
     # ---------------------------------------------------------------------------------------
     # forward / backward drivers (kernel sequences)
     # ---------------------------------------------------------------------------------------
+    def _drop_path_scales(self, B, dev):
+        """DropPath factors of this training forward: per block with a non-zero rate the pair (attention branch, MLP branch) of fp32 [B]
+        tensors keep_b / keep_prob, drawn in the reference's order (vit.py:397-398: the attention branch first); None for the other blocks.
+        `self.drop_path_sampler(block, branch, B, device) -> 0/1 tensor [B]` replaces the draw (tests pin the reference's masks with it,
+        as hcs_sampler does for the channel subsets: device random streams do not reproduce across devices)."""
+        rates = self.feature_extractor.drop_path_rates
+        if not self.training or not any(r > 0 for r in rates):
+            return None
+        out = []
+        for bi, r in enumerate(rates):
+            if r <= 0:
+                out.append(None)
+                continue
+            pair = []
+            for branch in ("attn", "mlp"):
+                if self.drop_path_sampler is not None:
+                    keep = self.drop_path_sampler(bi, branch, B, dev).to(device=dev, dtype=torch.float32).reshape(B)
+                else:
+                    keep = torch.floor((1.0 - r) + torch.rand(B, device=dev, dtype=torch.float32))  # vit.py:42-43
+                pair.append((keep / (1.0 - r)).contiguous())
+            out.append(tuple(pair))
+        return out
+
     def _run_forward(self, x, ch_idx_dev, C, E, pos_tab, want_ortho, save, keep=None, st_scale=None, st_shift=None, tok=None):
         fe = self.feature_extractor
         D, H = self.dim, fe.num_heads
@@ -587,9 +610,11 @@ class DiChaViT(nn.Module):
         layers = []
         xcur = xs.view(M, D)
         final_stride = N * D
+        drop = self._drop_path_scales(B, dev)
         for bi, blk in enumerate(fe.blocks):
             L = {}
             tail = self.cls_only_tail and bi == len(fe.blocks) - 1
+            dsc = drop[bi] if drop is not None else None  # (attention branch, MLP branch) factors [B] or None
             u1 = torch.empty(M, D, dtype=bf, device=dev)
             mean1, rstd1 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
             hip.ln_fwd(xcur, blk.norm1.weight, blk.norm1.bias, u1, mean1, rstd1, M, D, LN_EPS)
@@ -606,13 +631,15 @@ class DiChaViT(nn.Module):
                 o_c = o.view(B, N, D)[:, 0].contiguous()
                 x_c = xcur.view(B, N, D)[:, 0].contiguous()
                 xmid = torch.empty(B, D, dtype=f32, device=dev)
-                hip.gemm_nt(o_c, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=x_c)
+                hip.gemm_nt(o_c, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=x_c,
+                            **(dict(aux2=dsc[0], T=1) if dsc else {}))
                 R = B  # rows the rest of this block works on
             else:
                 hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale)
                 o_c = None
                 xmid = torch.empty(M, D, dtype=f32, device=dev) if save else xcur
-                hip.gemm_nt(o, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=xcur)
+                hip.gemm_nt(o, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=xcur,
+                            **(dict(aux2=dsc[0], T=N) if dsc else {}))
                 R = M
             u2 = torch.empty(R, D, dtype=bf, device=dev)
             mean2, rstd2 = torch.empty(R, dtype=f32, device=dev), torch.empty(R, dtype=f32, device=dev)
@@ -621,8 +648,10 @@ class DiChaViT(nn.Module):
             hact = torch.empty(R, 4 * D, dtype=bf, device=dev)
             hip.gemm_nt(u2, self._bf(blk.mlp.fc1.weight), hip.EPI_BIAS_GELU_BF16, z, bias=blk.mlp.fc1.bias, out2=hact)
             xout = torch.empty(R, D, dtype=f32, device=dev) if (save or tail) else xmid
-            hip.gemm_nt(hact, self._bf(blk.mlp.fc2.weight), hip.EPI_BIAS_RESID_F32, xout, bias=blk.mlp.fc2.bias, aux=xmid)
+            hip.gemm_nt(hact, self._bf(blk.mlp.fc2.weight), hip.EPI_BIAS_RESID_F32, xout, bias=blk.mlp.fc2.bias, aux=xmid,
+                        **(dict(aux2=dsc[1], T=R // B) if dsc else {}))
             if save:
+                L.update(drop=dsc)
                 L.update(x_in=xcur, u1=u1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x_mid=xmid, u2=u2, mean2=mean2,
                          rstd2=rstd2, z=z, h=hact, tail=tail, o_c=o_c)
                 layers.append(L)
@@ -682,7 +711,16 @@ class DiChaViT(nn.Module):
         hip.ln_bwd(dfeat, st["x_final"], st["meanf"], st["rstdf"], fe.norm.weight, None, dx, None, g(fe.norm.weight), g(fe.norm.bias),
                    B, D, x_row_stride=fs, dx_row_stride=fs)
         dxb = torch.empty_like(dx, dtype=bf)
-        hip.cast_bf16(dx, dxb, dx.numel())
+        # DropPath (vit.py:37-56): the gradient that enters a residual branch is the stream's gradient times that branch's per-sample
+        # factor.  The bf16 copy `dxb` is what the branch's backward reads (input gradient and weight gradient), so the factor goes into
+        # the copy — here for the last block's MLP branch, below inside every LayerNorm backward for the branch under it; the fp32
+        # stream `dx` itself stays unscaled.
+        top = st["layers"][-1].get("drop")
+        if top is not None:
+            rows = dx.shape[0] // B
+            dxb.copy_((dx.view(B, rows, D) * top[1].view(B, 1, 1)).view_as(dx))
+        else:
+            hip.cast_bf16(dx, dxb, dx.numel())
         if dp is not None:
             dp.grad_ready(ga, *self._range_of([fe.norm.weight, fe.norm.bias]))
         scale = 64 ** -0.5
@@ -744,7 +782,9 @@ class DiChaViT(nn.Module):
             if side is not None:
                 dxb, dxb_alt = dxb_alt, dxb  # the fc2 weight gradient may still be reading the old one
             before_write(id(dxb))
-            hip.ln_bwd(du_, L["x_mid"], L["mean2"], L["rstd2"], blk.norm2.weight, dx, dx, dxb, g(blk.norm2.weight), g(blk.norm2.bias), R, D)
+            dsc = L.get("drop")  # this block's (attention, MLP) DropPath factors: the copy written here feeds its attention branch
+            hip.ln_bwd(du_, L["x_mid"], L["mean2"], L["rstd2"], blk.norm2.weight, dx, dx, dxb, g(blk.norm2.weight), g(blk.norm2.bias), R, D,
+                       **(dict(bf16_row_scale=dsc[0], rows_per_sample=R // B) if dsc else {}))
             # attention
             if tail:
                 dO_c = du[B:2 * B]  # scratch rows of the same buffer
@@ -766,7 +806,9 @@ class DiChaViT(nn.Module):
             if side is not None:
                 dxb, dxb_alt = dxb_alt, dxb
             before_write(id(dxb))
-            hip.ln_bwd(du, L["x_in"], L["mean1"], L["rstd1"], blk.norm1.weight, dx, dx, dxb, g(blk.norm1.weight), g(blk.norm1.bias), M, D)
+            below = st["layers"][li - 1].get("drop") if li > 0 else None  # the copy written here feeds the MLP branch of the block below
+            hip.ln_bwd(du, L["x_in"], L["mean1"], L["rstd1"], blk.norm1.weight, dx, dx, dxb, g(blk.norm1.weight), g(blk.norm1.bias), M, D,
+                       **(dict(bf16_row_scale=below[1], rows_per_sample=N) if below else {}))
             if side is not None:
                 held.append(dict(L))  # the side stream may still be reading the saved activations
             L.clear()
@@ -842,12 +884,21 @@ class DiChaViT(nn.Module):
         if Cin != len(cur_channels):
             raise ValueError(f"input has {Cin} channels but mapper['{chunk_name}'] lists {len(cur_channels)}")
         ch_t = self._index_tensor(cur_channels, torch.int64, x.device)
-        channel_embed = pe.channel_embed(ch_t)  # [Cin, D]  :122
+        if pe.use_channelvit_channels:
+            channel_embed = pe.channel_embed(ch_t)  # [Cin, D]  :121-122
+        else:
+            # the reference leaves `channel_embed` unbound in this mode: everything that reads it fails there too
+            if (_cfg_get(cfg, "proxy_loss_lambda", 0) or 0) > 0:
+                raise UnboundLocalError("local variable 'channel_embed' referenced before assignment "
+                                        "(proxy_loss_lambda > 0 needs use_channelvit_channels=True; models/dichavit.py:399-402)")
+            if self.training and pe.enable_sample and _cfg_get(cfg, "hcs_sampling", "none") not in ("none", None) and self.hcs_sampler is None:
+                raise AssertionError("hcs_sampling only works with use_channelvit_channels=True")  # :150-152
+            channel_embed = torch.zeros(Cin, self.dim, device=x.device)  # the tokeniser epilogue adds aux[c]: zeros = no offset (:409)
         idx = list(range(Cin))
         if self.training and pe.enable_sample:  # :127
             cur_channels, idx = self._sample_channels(chunk_name, cur_channels, channel_embed, x)
             channel_embed = channel_embed[idx]  # :136/212
-        if (not self.training) and (training_chunks is not None):  # :219
+        if pe.use_channelvit_channels and (not self.training) and (training_chunks is not None):  # :219
             channel_embed = self._eval_channel_embed(chunk_name, training_chunks, new_channel_init)
         C = len(idx)
         P = fe.patch_size

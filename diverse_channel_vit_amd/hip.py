@@ -31,6 +31,7 @@ _SIGS = {
     "dcv_ln_bwd": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp], _i),
     "dcv_ln_bwd_det_ws_floats": ([_i, _i], _l),
     "dcv_ln_bwd_det": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp, _l, _vp], _i),
+    "dcv_ln_bwd_scaled": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _l, _vp], _i),
     "dcv_patch_bwd_det_ws_floats": ([_i, _i, _i, _i], _l),
     "dcv_patch_bwd_det": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _vp], _i),
     "dcv_ortho_fwd_det_ws_floats": ([_i, _i, _i, _i], _l),
@@ -257,15 +258,20 @@ def ln_fwd(x, gamma, beta, out, mean, rstd, M, D, eps, x_row_stride=None):
     _check(rc, "dcv_ln_fwd")
 
 
-def ln_bwd(du, x, mean, rstd, gamma, dx_in, dx_out, dx_bf16, dgamma, dbeta, M, D, x_row_stride=None, dx_row_stride=None):
+def ln_bwd(du, x, mean, rstd, gamma, dx_in, dx_out, dx_bf16, dgamma, dbeta, M, D, x_row_stride=None, dx_row_stride=None,
+           bf16_row_scale=None, rows_per_sample=1):
+    """bf16_row_scale [M / rows_per_sample] (fp32): dx_bf16 = bf16(scale[row / rows_per_sample] * dx_out) (DropPath, dcv_ln_bwd_scaled)."""
     with _timer(lambda: (f"ln_bwd_kernel<{'true' if du.dtype == torch.float32 else 'false'}, {2 if D <= 512 else 4}>", f"M{M} D{D}", 0.0, None,
                          M * D * ((4.0 if du.dtype == torch.float32 else 2.0) + 4.0 + (4.0 if dx_in is not None else 0.0) + 4.0 + (2.0 if dx_bf16 is not None else 0.0)))):
         lib = load()
         args = (_p(du), 1 if du.dtype == torch.float32 else 0, _p(x), D if x_row_stride is None else x_row_stride,
                 _p(mean), _p(rstd), _p(gamma), _p(dx_in), _p(dx_out), D if dx_row_stride is None else dx_row_stride,
                 _p(dx_bf16), _p(dgamma), _p(dbeta), M, D)
-        if _deterministic:
-            ws = _workspace(_ws_size(lib.dcv_ln_bwd_det_ws_floats(M, D)), dx_out)
+        ws = _workspace(_ws_size(lib.dcv_ln_bwd_det_ws_floats(M, D)), dx_out) if _deterministic else None
+        if bf16_row_scale is not None:
+            _req(bf16_row_scale, torch.float32, "bf16_row_scale")
+            rc = lib.dcv_ln_bwd_scaled(*args, _p(bf16_row_scale), rows_per_sample, _p(ws), ws.numel() if ws is not None else 0, _stream())
+        elif ws is not None:
             rc = lib.dcv_ln_bwd_det(*args, _p(ws), ws.numel(), _stream())
         else:
             rc = lib.dcv_ln_bwd(*args, _stream())

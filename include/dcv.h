@@ -29,7 +29,9 @@ extern "C" {
 /* dcv_gemm_nt epilogues */
 #define DCV_EPI_BIAS_BF16 0      /* out bf16 = acc + bias                         (attn.qkv, vit.py:123)            */
 #define DCV_EPI_BIAS_GELU_BF16 1 /* z = acc + bias (fp32): out bf16 = GELU_erf'(z), out2 bf16 = GELU_erf(z) (mlp.fc1 + act, vit.py:77-78) */
-#define DCV_EPI_BIAS_RESID_F32 2 /* out f32 = (aux f32 ? aux : out) + acc + bias (attn.proj / mlp.fc2 + residual, vit.py:142,397-398) */
+#define DCV_EPI_BIAS_RESID_F32 2 /* out f32 = (aux f32 ? aux : out) + s (acc + bias) (attn.proj / mlp.fc2 + residual, vit.py:142,397-398);
+                                    s = 1, or with aux2 != NULL and T = rows per sample: s = aux2[row / T] — DropPath's per-sample
+                                    keep_b / keep_prob (vit.py:37-56) */
 #define DCV_EPI_PLAIN_BF16 3     /* out bf16 = acc                                 (input gradients)                */
 #define DCV_EPI_GELU_BWD_BF16 4  /* out bf16 = acc * aux bf16, aux = the saved GELU'(z)  (grad through act, vit.py:78)    */
 #define DCV_EPI_PATCH 5          /* tokens: out f32[b,1+t,:] = acc + bias + aux[c(t),:] + aux2[1+i(t),:] ;
@@ -98,6 +100,13 @@ int dcv_ortho_fwd_det(const float* Y, float* S, float* selfsq, float* tot, float
                       float* ws, long ws_floats, void* stream);
 long dcv_sumsq_det_ws_floats(long n);
 int dcv_sumsq_acc_det(const float* x, long n, float* acc, float* ws, long ws_floats, void* stream);
+
+/* dcv_ln_bwd with the bf16 copy scaled per sample: dx_bf16 = bf16(bf16_row_scale[row / rows_per_sample] * dx_out) — the copy feeds the
+ * backward of the residual branch below this LayerNorm, whose DropPath factor (vit.py:37-56) multiplies that branch's gradient; dx_out itself
+ * (the residual stream) is not scaled.  ws NULL: atomic dgamma / dbeta; else the deterministic form (dcv_ln_bwd_det_ws_floats floats). */
+int dcv_ln_bwd_scaled(const void* du, int du_is_f32, const float* x, long x_row_stride, const float* mean, const float* rstd,
+                      const float* gamma, const float* dx_in, float* dx_out, long dx_row_stride, void* dx_bf16, float* dgamma,
+                      float* dbeta, int M, int D, const float* bf16_row_scale, int rows_per_sample, float* ws, long ws_floats, void* stream);
 
 /* softmax(q k^T * scale) v for packed qkv [B,N,3,H,64] bf16 -> o [B,N,H*64] bf16, lse [B,H,N] f32.
  * Replaces Attention.forward's q@k^T / softmax / @v (vit.py:123-141); the [B,H,N,N] matrix is never stored. */

@@ -229,8 +229,12 @@ def tokenise(sd: Dict[str, Tensor], x: Tensor, cfg, ch_ids: Sequence[int], idx: 
     if lam_o > 0:  # :378-389
         extra = extra + lam_o * ortho_loss_linear(
             Y, C, n, cfg["gamma_s"], cfg["gamma_d"], cfg["reverse_pos_pairs"], cfg["use_square"])
-    E_all = sd["feature_extractor.patch_embed.channel_embed.weight"]
-    E = E_all[list(ch_ids)] if channel_embed_rows is None else channel_embed_rows  # :122,136/212
+    if not cfg.get("use_channelvit_channels", True):  # :83-95, 121, 409: no channel_embed parameter, no channel offset on the tokens
+        assert lam_p == 0, "the reference leaves channel_embed unbound in this mode: the proxy term cannot be evaluated"
+        E = torch.zeros(C, Y.shape[-1], dtype=Y.dtype)
+    else:
+        E_all = sd["feature_extractor.patch_embed.channel_embed.weight"]
+        E = E_all[list(ch_ids)] if channel_embed_rows is None else channel_embed_rows  # :122,136/212
     if lam_p > 0:  # :399-402
         Pr = sd["feature_extractor.patch_embed.channel_emb_proxies"][list(ch_ids)]
         s = math.sqrt(1.0 / cfg["temperature"])  # :60
@@ -245,7 +249,9 @@ def tokenise(sd: Dict[str, Tensor], x: Tensor, cfg, ch_ids: Sequence[int], idx: 
 # --------------------------------------------------------------------------------------
 # encoder (models/vit.py:59-82, 101-144, 346-399; models/dichavit.py:645-652)
 # --------------------------------------------------------------------------------------
-def block_forward(sd: Dict[str, Tensor], pre: str, z: Tensor, heads: int) -> Tensor:
+def block_forward(sd: Dict[str, Tensor], pre: str, z: Tensor, heads: int, drop: Optional[Tuple[Tensor, Tensor, float]] = None) -> Tensor:
+    """drop = (keep mask of the attention branch [B], keep mask of the MLP branch [B], keep probability): stochastic depth, vit.py:37-56,
+    397-398 — each residual branch of sample b is multiplied by mask_b / keep_prob."""
     B, N, D = z.shape
     hd = D // heads
     u = F.layer_norm(z, (D,), sd[pre + "norm1.weight"], sd[pre + "norm1.bias"], LN_EPS)
@@ -255,16 +261,35 @@ def block_forward(sd: Dict[str, Tensor], pre: str, z: Tensor, heads: int) -> Ten
     att = (q @ k.transpose(-2, -1)) * hd ** -0.5  # vit.py:126 (scale after the product)
     att = att.softmax(dim=-1)
     o = (att @ v).transpose(1, 2).reshape(B, N, D)
-    z = z + o @ sd[pre + "attn.proj.weight"].t() + sd[pre + "attn.proj.bias"]
+    sa = sm = 1.0
+    if drop is not None:
+        sa = (drop[0].to(z.dtype) / drop[2]).view(B, 1, 1)
+        sm = (drop[1].to(z.dtype) / drop[2]).view(B, 1, 1)
+    z = z + sa * (o @ sd[pre + "attn.proj.weight"].t() + sd[pre + "attn.proj.bias"])
     u = F.layer_norm(z, (D,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], LN_EPS)
     hdn = F.gelu(u @ sd[pre + "mlp.fc1.weight"].t() + sd[pre + "mlp.fc1.bias"])  # exact erf GELU
-    return z + hdn @ sd[pre + "mlp.fc2.weight"].t() + sd[pre + "mlp.fc2.bias"]
+    return z + sm * (hdn @ sd[pre + "mlp.fc2.weight"].t() + sd[pre + "mlp.fc2.bias"])
 
 
-def encode(sd: Dict[str, Tensor], z: Tensor, cfg) -> Tensor:
+def drop_path_rates(cfg) -> List[float]:
+    """Per-block drop probabilities: linspace(0, drop_path_rate, depth) (models/dichavit.py:475); block 0 never drops."""
+    _, depth, _ = MODEL_SIZES[cfg["pretrained_model_name"]]
+    r = float(cfg.get("drop_path_rate", 0.0) or 0.0)
+    return [float(v) for v in torch.linspace(0, r, depth)]
+
+
+def encode(sd: Dict[str, Tensor], z: Tensor, cfg, drop_masks: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """drop_masks (training with drop_path_rate > 0): the 0/1 keep masks [B] in the order the reference draws them — for every block with
+    a non-zero rate, the attention branch then the MLP branch (vit.py:397-398)."""
     D, depth, heads = MODEL_SIZES[cfg["pretrained_model_name"]]
+    dpr = drop_path_rates(cfg)
+    k = 0
     for i in range(depth):
-        z = block_forward(sd, f"feature_extractor.blocks.{i}.", z, heads)
+        drop = None
+        if drop_masks is not None and dpr[i] > 0.0:
+            drop = (drop_masks[k], drop_masks[k + 1], 1.0 - dpr[i])
+            k += 2
+        z = block_forward(sd, f"feature_extractor.blocks.{i}.", z, heads, drop)
     f = F.layer_norm(z, (D,), sd["feature_extractor.norm.weight"], sd["feature_extractor.norm.bias"], LN_EPS)
     return f[:, 0]  # dichavit.py:651-652
 
@@ -290,21 +315,22 @@ def token_keep(mode: Optional[str], nc: int, n: int, rng: _pyrandom.Random) -> O
 
 
 def forward(sd: Dict[str, Tensor], x: Tensor, cfg, ch_ids: Sequence[int], idx: Sequence[int],
-            channel_embed_rows: Optional[Tensor] = None, keep: Optional[Sequence[int]] = None) -> Tuple[Tensor, Tensor]:
+            channel_embed_rows: Optional[Tensor] = None, keep: Optional[Sequence[int]] = None,
+            drop_masks: Optional[Sequence[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """DiChaViT.forward (models/dichavit.py:844-861).  Returns (logits-or-features, extra).
-    keep: token positions that survive dropout_tokens_hcs (from token_keep)."""
+    keep: token positions that survive dropout_tokens_hcs (from token_keep); drop_masks: see encode."""
     z, extra = tokenise(sd, x, cfg, ch_ids, idx, channel_embed_rows)
     if keep is not None:
         z = z[:, list(keep)]
-    f = encode(sd, z, cfg)
+    f = encode(sd, z, cfg, drop_masks)
     if "classifer_head.weight" in sd:  # absent for CHAMMI (dichavit.py:797-801)
         f = f @ sd["classifer_head.weight"].t() + sd["classifer_head.bias"]
     return f, extra
 
 
-def train_loss(sd, x, y, cfg, ch_ids, idx, extra_loss_lambda: float = 1.0, keep=None):
+def train_loss(sd, x, y, cfg, ch_ids, idx, extra_loss_lambda: float = 1.0, keep=None, drop_masks=None):
     """train_one_batch_regular's loss (trainer.py:986-995)."""
-    logits, extra = forward(sd, x, cfg, ch_ids, idx, keep=keep)
+    logits, extra = forward(sd, x, cfg, ch_ids, idx, keep=keep, drop_masks=drop_masks)
     main = F.cross_entropy(logits, y)
     return main + extra_loss_lambda * extra, main, extra, logits
 
@@ -423,6 +449,8 @@ def state_shapes(cfg, n_channels: int, img: int, num_classes: int, chammi: bool 
         fe + "patch_embed.proj.bias": (D,),
         fe + "patch_embed.channel_embed.weight": (n_channels, D),
     }
+    if not cfg.get("use_channelvit_channels", True):
+        del sh[fe + "patch_embed.channel_embed.weight"]
     if (cfg.get("proxy_loss_lambda", 0) or 0) > 0:
         sh[fe + "patch_embed.channel_emb_proxies"] = (n_channels, D)
     for i in range(depth):

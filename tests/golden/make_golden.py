@@ -477,6 +477,50 @@ def case_base32_train(dichavit, loss_fn):
     _train_case(dichavit, "base32_train", base_cfg(pretrained_model_name="base"), {"train": list(range(32))}, "train", 32, 32, 224, 161, 1, 131, stages=False)
 
 
+def case_nochannel_embed(dichavit, loss_fn):
+    """use_channelvit_channels=False (models/dichavit.py:83-95, 121, 409): no channel_embed parameter, tokens carry no channel offset.
+    The reference leaves `channel_embed` unbound in this mode, so the proxy term must be off (proxy_loss_lambda = 0); the diversity loss
+    stays on.  One train step of a So2Sat-shaped model + a step with random channel sampling (enable_sample, hcs_sampling = none)."""
+    cfg = base_cfg(use_channelvit_channels=False, proxy_loss_lambda=0.0, patch_size=8)
+    _train_case(dichavit, "nochannel_embed", cfg, {"train": list(range(6))}, "train", 6, 6, 32, 9, 3, 141, stages=False)
+
+
+def case_drop_path(dichavit, loss_fn):
+    """drop_path_rate > 0 (stochastic depth; vit.py:37-56, 397-398; per-block rates linspace(0, rate, depth), dichavit.py:475): one train
+    step of a So2Sat-shaped model at batch 6, rate 0.4.  The reference draws its keep masks with torch.rand on the model's device; the
+    draws are recorded here (torch.rand is wrapped for the duration of the forward) so that the tests can inject the same masks."""
+    cfg = base_cfg(drop_path_rate=0.4, patch_size=8)
+    mapper = {"train": list(range(6))}
+    model, keys = build(dichavit, cfg, mapper, 6, 32, 9, 151)
+    model.train()
+    x, y = orc.make_batch(152, 6, 6, 32, 9)
+    masks = []
+    real_rand = torch.rand
+
+    def rec_rand(*a, **kw):
+        r = real_rand(*a, **kw)
+        masks.append(r.clone())
+        return r
+
+    torch.manual_seed(4242)
+    torch.rand = rec_rand
+    try:
+        out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    finally:
+        torch.rand = real_rand
+    main = torch.nn.CrossEntropyLoss()(out, y)
+    loss = main + 1.0 * extra
+    loss.backward()
+    dpr = orc.drop_path_rates(cfg)
+    rates = [r for r in dpr if r > 0 for _ in range(2)]
+    assert len(masks) == len(rates) == 22 and all(m.shape == (6, 1, 1) for m in masks)
+    keep = np.stack([np.floor((1.0 - r) + m.reshape(-1).numpy()) for r, m in zip(rates, masks)]).astype(np.float32)  # [22, B] of 0 / 1
+    print(f"  drop_path: loss={loss.item():.6f} kept {keep.mean():.3f} of the branches")
+    arrays = dict(logits=out.detach().numpy(), extra=np.array(extra.item()), main=np.array(main.item()), loss=np.array(loss.item()), keep=keep)
+    arrays.update(grad_summary(model))
+    save("drop_path", dict(cfg=cfg, mapper=mapper, chunk="train", n_channels=6, C_in=6, img=32, num_classes=9, B=6, seed=151, state_keys=keys), arrays)
+
+
 def case_resolution_quirk(dichavit, loss_fn):
     """interpolate_pos_encoding's early-out (dichavit.py:529-530) hit with SEVERAL channels: a 32-px / P8 model (16 grid
     positions) fed 16-px images with 4 channels has 4 x 4 = 16 patch tokens = the model's own count, and H == W: the raw
@@ -573,7 +617,7 @@ def case_init_stats(dichavit, loss_fn):
 CASES = dict(tokendrop=case_tokendrop, resolution=case_resolution, schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
              chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, resume=case_resume,
              chammi_hcs=case_chammi_hcs, jumpcp_b16=case_jumpcp_b16, base64=case_base64, resolution_quirk=case_resolution_quirk,
-             hcs_proj=case_hcs_proj, init_stats=case_init_stats, base32_train=case_base32_train)
+             hcs_proj=case_hcs_proj, init_stats=case_init_stats, base32_train=case_base32_train, nochannel_embed=case_nochannel_embed, drop_path=case_drop_path)
 
 if __name__ == "__main__":
     torch.set_num_threads(8)

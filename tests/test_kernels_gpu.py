@@ -227,6 +227,39 @@ def test_gemm_tn_wide_ragged_reduction(hip, M):
     _check_gemm_tn(hip, M, 384, 128, tile=hip.TILE_WIDE)
 
 
+def test_drop_path_kernel_hooks(hip):
+    """The two places DropPath touches the kernels: dcv_gemm_nt's residual epilogue with a per-sample branch factor (aux2, T rows per
+    sample) on both tile shapes, and dcv_ln_bwd_scaled's per-sample factor on the bf16 copy only (dx_out, dgamma, dbeta unchanged)."""
+    B, N, D, K = 6, 700, 384, 1536
+    M = B * N
+    A, W, bias = _bf(M, K, seed=1), _bf(D, K, scale=0.05, seed=2), _f(D, scale=0.1, seed=3)
+    x0 = _f(M, D, seed=4)
+    sc = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 1.25], device="cuda")
+    ref = x0 + sc.repeat_interleave(N)[:, None] * (A.float() @ W.float().t() + bias)
+    for tile in (hip.TILE_NARROW, hip.TILE_WIDE):
+        y = torch.empty_like(x0)
+        hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, y, bias=bias, aux=x0, aux2=sc, T=N, tile=tile)
+        _close(y, ref, 1e-4, 2e-4 * math.sqrt(K), f"resid with branch factor, tile {tile}")
+        assert torch.equal(y.view(B, N, D)[0], x0.view(B, N, D)[0])  # a dropped sample keeps its residual bit for bit
+    with pytest.raises(RuntimeError):
+        hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, y, bias=bias, aux=x0, aux2=sc, T=0)
+    # LayerNorm backward
+    x, du, dx_in = _f(M, D, scale=2.0, seed=5), _bf(M, D, seed=6), _f(M, D, seed=7)
+    g, b = 1 + 0.1 * _f(D, seed=8), 0.1 * _f(D, seed=9)
+    u = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    hip.ln_fwd(x, g, b, u, mean, rstd, M, D, 1e-6)
+    outs = []
+    for scale in (None, sc):
+        dx, dxb = torch.empty(M, D, device="cuda"), torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+        dg, db = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda")
+        hip.ln_bwd(du, x, mean, rstd, g, dx_in, dx, dxb, dg, db, M, D, **(dict(bf16_row_scale=scale, rows_per_sample=N) if scale is not None else {}))
+        outs.append((dx, dxb, dg, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    want = (outs[0][0].view(B, N, D) * sc.view(B, 1, 1)).to(torch.bfloat16).view(M, D)
+    assert torch.equal(outs[1][1], want)
+
+
 @pytest.mark.parametrize("M,D", [(1000, 384), (37, 192), (513, 768)])
 def test_layernorm(hip, M, D, reduction_mode):
     x = _f(M, D, scale=2.0, seed=1) + 0.5

@@ -105,6 +105,98 @@ def test_train_step_parity(gpu_device, name):
     print(f"{name}: loss {loss.item():.6f} (ref {loss_ref:.6f}) worst grad rel err {worst}")
 
 
+def test_no_channel_embed_mode(gpu_device):
+    """use_channelvit_channels=False (VERDICT r2 missing 7; models/dichavit.py:83-95, 121, 409): the model has no channel_embed parameter
+    (state dict without that key), the tokeniser adds no channel offset; one train step against the real reference's golden and the oracle;
+    and the combinations the reference itself cannot run in this mode fail the same way."""
+    meta, a = load_golden("nochannel_embed")
+    model, _ = build(meta, gpu_device)
+    assert not any("channel_embed" in k for k in model.state_dict())
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], meta["C_in"], meta["img"], meta["num_classes"])
+    out, extra = model(x.to(gpu_device), meta["chunk"], None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    loss = torch.nn.CrossEntropyLoss()(out, y.to(gpu_device)) + extra
+    loss.backward()
+    lg = a["logits"]
+    assert np.abs(out.detach().cpu().numpy() - lg).max() <= 3e-2 * np.abs(lg).max()
+    assert abs(extra.item() - float(a["extra"])) <= 2e-2 * abs(float(a["extra"])) + 1e-6
+    assert abs(loss.item() - float(a["loss"])) <= 5e-3
+    _golden_grad_check(model, a)
+    ch = meta["mapper"][meta["chunk"]]
+    sd_ref, *_ = oracle_grads(meta, x, y, ch, list(range(len(ch))))
+    check_grads(model, sd_ref)
+    # random channel subsets (enable_sample, hcs_sampling = none) work without embeddings ...
+    model.feature_extractor.patch_embed.enable_sample = True
+    random.seed(5)
+    o2, _ = model(x.to(gpu_device), meta["chunk"], None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    assert o2.shape == out.shape
+    # ... embedding-driven sampling does not (the reference asserts, :150-152), nor does the proxy term (unbound channel_embed, :399-402)
+    model.cfg["hcs_sampling"] = "lowest_cosine_prob"
+    with pytest.raises(AssertionError):
+        model(x.to(gpu_device), meta["chunk"], None)
+    model.cfg["hcs_sampling"] = "none"
+    model.cfg["proxy_loss_lambda"] = 0.001
+    with pytest.raises(UnboundLocalError):
+        model(x.to(gpu_device), meta["chunk"], None)
+
+
+def test_drop_path_parity(gpu_device):
+    """drop_path_rate = 0.4 (VERDICT r2 missing 6; stochastic depth, vit.py:37-56, 397-398; per-block rates linspace(0, rate, depth)): one
+    train step with the keep masks the REAL reference drew (tests/golden/drop_path.npz; injected through model.drop_path_sampler, as the
+    HCS subsets are) against its logits, losses and every gradient, and against the oracle with the same masks.  Forward: the residual
+    epilogues multiply the branch by keep_b / keep_prob; backward: the bf16 copy of the stream's gradient that feeds a branch carries
+    the same factor (dcv_ln_bwd_scaled)."""
+    meta, a = load_golden("drop_path")
+    model, _ = build(meta, gpu_device)
+    model.stochastic_weight_rounding = False
+    rates = model.feature_extractor.drop_path_rates
+    assert rates[0] == 0.0 and abs(rates[-1] - 0.4) < 1e-6
+    order = [(bi, br) for bi, r in enumerate(rates) if r > 0 for br in ("attn", "mlp")]
+    masks = {k: torch.from_numpy(a["keep"][i]) for i, k in enumerate(order)}
+    asked = []
+
+    def sampler(bi, branch, B, dev):
+        asked.append((bi, branch))
+        return masks[(bi, branch)]
+
+    model.drop_path_sampler = sampler
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], meta["C_in"], meta["img"], meta["num_classes"])
+    out, extra = model(x.to(gpu_device), meta["chunk"], None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    assert asked == order  # the reference's draw order: every block with a non-zero rate, attention branch first
+    loss = torch.nn.CrossEntropyLoss()(out, y.to(gpu_device)) + extra
+    loss.backward()
+    lg = a["logits"]
+    assert np.abs(out.detach().cpu().numpy() - lg).max() <= 3e-2 * np.abs(lg).max()
+    assert abs(loss.item() - float(a["loss"])) <= 5e-3
+    _golden_grad_check(model, a)
+    shapes = orc.state_shapes(meta["cfg"], meta["n_channels"], meta["img"], meta["num_classes"])
+    sd = orc.make_state(shapes, meta["seed"], dtype=torch.float64)
+    for v in sd.values():
+        v.requires_grad_(True)
+    ch = meta["mapper"][meta["chunk"]]
+    l_ref, *_ = orc.train_loss(sd, x.double(), y, meta["cfg"], ch, list(range(len(ch))), drop_masks=[masks[k] for k in order])
+    l_ref.backward()
+    check_grads(model, sd)
+    # eval mode: no drop, no draw
+    model.eval()
+    asked.clear()
+    with torch.inference_mode():
+        oe = model(x.to(gpu_device), meta["chunk"], None)
+    assert not asked
+    ref_eval, _ = orc.forward({k: v.detach() for k, v in sd.items()}, x.double(), meta["cfg"], ch, list(range(len(ch))))
+    assert (oe.cpu().double() - ref_eval).abs().max().item() <= 3e-2 * ref_eval.abs().max().item()
+    # the default sampler: Bernoulli(keep_prob) masks on the device, scaled by 1 / keep_prob
+    model.train()
+    model.drop_path_sampler = None
+    torch.manual_seed(0)
+    sc = model._drop_path_scales(4096, gpu_device)
+    assert sc[0] is None
+    for bi in (1, 6, 11):
+        keep = 1.0 - rates[bi]
+        for t in sc[bi]:
+            vals = set(np.round(t.unique().cpu().numpy(), 5).tolist())
+            assert vals <= {0.0, round(1.0 / keep, 5)} and abs((t > 0).float().mean().item() - keep) < 0.04
+
+
 def test_hcs_subsets_parity(gpu_device):
     meta, a = load_golden("hcs")
     model, _ = build(meta, gpu_device)

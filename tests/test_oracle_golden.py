@@ -294,3 +294,35 @@ def test_headline_b16_golden_forward():
     with torch.no_grad():
         logits, extra = orc.forward(sd, x[:2], meta["cfg"], list(range(8)), list(range(8)))
     assert np.abs(logits.numpy() - a["logits"][:2]).max() < 5e-5
+
+
+def test_no_channel_embed_golden():
+    """use_channelvit_channels=False (models/dichavit.py:83-95, 121, 409; tests/golden/nochannel_embed.npz from the real reference): the state
+    has no channel_embed entry, the tokens carry no channel offset; logits, losses and every gradient of one train step."""
+    meta, a = load_golden("nochannel_embed")
+    assert not any("channel_embed" in k for k in meta["state_keys"])
+    sd = _state(meta)
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], meta["C_in"], meta["img"], meta["num_classes"], dtype=torch.float64)
+    ch = meta["mapper"][meta["chunk"]]
+    loss, main, extra, logits = orc.train_loss(sd, x, y, meta["cfg"], ch, list(range(len(ch))))
+    loss.backward()
+    assert np.abs(logits.detach().numpy() - a["logits"]).max() < 2e-5
+    assert abs(extra.item() - float(a["extra"])) < 1e-6 * max(1, abs(float(a["extra"]))) + 2e-8
+    assert abs(loss.item() - float(a["loss"])) < 5e-6
+    _check_grads(sd, a)
+
+
+def test_drop_path_golden():
+    """drop_path_rate = 0.4 (stochastic depth, vit.py:37-56, 397-398; tests/golden/drop_path.npz from the real reference with its torch.rand
+    draws recorded): the oracle with the same keep masks reproduces logits, losses and every gradient."""
+    meta, a = load_golden("drop_path")
+    sd = _state(meta)
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], meta["C_in"], meta["img"], meta["num_classes"], dtype=torch.float64)
+    ch = meta["mapper"][meta["chunk"]]
+    masks = [torch.from_numpy(m) for m in a["keep"]]
+    assert len(masks) == 22 and set(np.unique(a["keep"]).tolist()) <= {0.0, 1.0} and 0 < a["keep"].mean() < 1
+    loss, main, extra, logits = orc.train_loss(sd, x, y, meta["cfg"], ch, list(range(len(ch))), drop_masks=masks)
+    loss.backward()
+    assert np.abs(logits.detach().numpy() - a["logits"]).max() < 2e-5
+    assert abs(loss.item() - float(a["loss"])) < 5e-6
+    _check_grads(sd, a)
