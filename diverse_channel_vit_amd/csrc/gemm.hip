@@ -608,9 +608,10 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         cur = nxt;
         L = Ln;
     }
-#if DCV_STAMP
-    if (tid == 0 && a.aux2 && EPI != DCV_EPI_PATCH) {
-        unsigned long long* sp = (unsigned long long*)a.aux2 + 4 * blockIdx.x;
+#if DCV_STAMP  // stamps leave through aux2, or through out2 for the residual epilogue (whose aux2 is the DropPath factor)
+    void* const stamp_out = (EPI == DCV_EPI_BIAS_RESID_F32) ? a.out2 : (void*)a.aux2;
+    if (tid == 0 && stamp_out && EPI != DCV_EPI_PATCH) {
+        unsigned long long* sp = (unsigned long long*)stamp_out + 4 * blockIdx.x;
         sp[0] = st_loop; sp[1] = st_epi; sp[2] = st_n; sp[3] = clock64();
     }
 #endif
@@ -844,14 +845,17 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         n0 = n0n;
         L = Ln;
     }
+#if DCV_STAMP  // stamps leave through aux2, or through out2 for the residual epilogue (whose aux2 is the DropPath factor)
+    void* const stamp_out = (EPI == DCV_EPI_BIAS_RESID_F32) ? a.out2 : (void*)a.aux2;
+#endif
 #if DCV_STAMP == 1
-    if (tid == 0 && a.aux2) {
-        unsigned long long* sp = (unsigned long long*)a.aux2 + 4 * blockIdx.x;
+    if (tid == 0 && stamp_out) {
+        unsigned long long* sp = (unsigned long long*)stamp_out + 4 * blockIdx.x;
         sp[0] = st_loop; sp[1] = st_epi; sp[2] = st_n; sp[3] = clock64();
     }
 #elif DCV_STAMP == 2
-    if (lane == 0 && a.aux2) {  // per wave: vmcnt wait, barrier wait, reads + DMA issue, MFMA steps, epilogue, tiles
-        unsigned long long* sp = (unsigned long long*)a.aux2 + 8 * (8 * blockIdx.x + wave);
+    if (lane == 0 && stamp_out) {  // per wave: vmcnt wait, barrier wait, reads + DMA issue, MFMA steps, epilogue, tiles
+        unsigned long long* sp = (unsigned long long*)stamp_out + 8 * (8 * blockIdx.x + wave);
         sp[0] = fs_vm; sp[1] = fs_bar; sp[2] = fs_issue; sp[3] = fs_mfma; sp[4] = st_epi; sp[5] = st_n; sp[6] = st_loop; sp[7] = 0;
     }
 #endif

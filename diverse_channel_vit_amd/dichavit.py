@@ -248,6 +248,7 @@ class DiChaViT(nn.Module):
         # --- HIP-path state (not part of the state_dict) ---
         self._arena = None
         self._grad_arena = None
+        self._grad_scratch = None
         self._dp = None  # set by diverse_channel_vit_amd.dp.DataParallel
         self.wgrad_stream = True  # the backward runs the weight-gradient GEMMs on a second HIP stream (_run_backward_body); False: one stream
         self._side = None
@@ -304,6 +305,7 @@ class DiChaViT(nn.Module):
         self._enc_off = offs[:len(enc)]
         self._enc_size = offs[len(enc)] if others else off
         self._grad_arena = None
+        self._grad_scratch = None
         self._bf16 = torch.empty(self._enc_size, dtype=torch.bfloat16, device=device)    # same offsets as the arena
         self._bf16_t = torch.empty(self._enc_size, dtype=torch.bfloat16, device=device)  # transposed copies of matrices
         # transposed copies are needed for the four Linear weights of every block (input-gradient GEMMs)
@@ -341,8 +343,12 @@ class DiChaViT(nn.Module):
         hip.cast_transpose_bf16(self._arena, self._bf16_t, self._tdesc, self._tdesc_n, self._tdesc_tiles)
 
     def _new_grad_arena(self):
-        """A zeroed flat gradient buffer for the encoder parameters.  The previous one is reused when no
-        parameter's .grad still aliases it (optimizer.zero_grad(set_to_none=True) flow)."""
+        """A zeroed flat gradient buffer for the encoder parameters.  The arena is reused when no parameter's .grad still aliases it
+        (optimizer.zero_grad(set_to_none=True) flow).  While .grad does alias it — the second and later backward passes of an optimiser
+        step (the CHAMMI step, trainer.py:846-935), or zero_grad(set_to_none=False) — the pass writes into a SCRATCH arena that autograd
+        then adds into .grad: `_grad_arena` keeps naming the buffer .grad lives in, so HipAdamW's one-launch update and clip_grad_norm_'s
+        one-launch norm still apply (repointing it here made every accumulating step fall back to ~150 per-parameter launches
+        and allocate 86 MB)."""
         ga = self._grad_arena
         if ga is not None:
             busy = any(p.grad is not None and p.grad.untyped_storage().data_ptr() == ga.untyped_storage().data_ptr()
@@ -350,6 +356,11 @@ class DiChaViT(nn.Module):
             if not busy:
                 ga.zero_()
                 return ga
+            sc = self._grad_scratch
+            if sc is None or sc.device != ga.device or sc.numel() != ga.numel():
+                sc = self._grad_scratch = torch.empty_like(ga)
+            sc.zero_()  # stream-ordered behind the previous pass's AccumulateGrad adds, which read it on this stream
+            return sc
         ga = torch.zeros(self._enc_size, dtype=torch.float32, device=self._arena.device)
         self._grad_arena = ga
         return ga

@@ -331,6 +331,46 @@ def test_attention_fwd_bwd(hip, B, N, H):
         _close(d[:, :, i], ref, 3e-2, tol, nm)
 
 
+def test_attention_at_the_bench_grid(hip):
+    """the three attention kernels at the bench's OWN launch — B = 64, H = 6, N = 1569: 384 (batch, head) pairs,
+    4 992 workgroups (the other tests stop at B x H = 96 at this N) — against an fp32 reference evaluated in chunks of 4 images (the [4, 6,
+    1569, 1569] fp32 score block is 236 MB).  Inputs are scaled like the model's (|q k| scores of a few units), with one spiked key per chunk
+    so that the online-softmax rescale path runs at this grid too."""
+    B, N, H = 64, 1569, 6
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = _bf(B, N, 3 * D, scale=1.2, seed=2024)
+    for b in range(0, B, 4):
+        qkv[b, N // 3, :64] *= 4
+        qkv[b, N - 5, D:D + 64] = qkv[b, N // 3, :64]
+    dO = _bf(B, N, D, seed=2025)
+    o = torch.empty(B, N, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    hip.attn_fwd(qkv, o, lse, B, N, H, 64, scale)
+    dqkv = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    delta = torch.empty(2, B, H, N, device="cuda")
+    hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, scale)
+    assert torch.isfinite(dqkv.float()).all()
+    worst = {}
+    for b0 in range(0, B, 4):
+        sl = slice(b0, b0 + 4)
+        qr = qkv[sl].float().requires_grad_(True)
+        o_ref, lse_ref = _attn_ref(qr, 4, N, H, scale)
+        o_ref.backward(dO[sl].float())
+        _close(o[sl], o_ref, 2e-2, 2e-2, f"attn O, images {b0}..")
+        _close(lse[sl], lse_ref, 1e-4, 2e-3, f"attn LSE, images {b0}..")
+        g = qr.grad.reshape(4, N, 3, D)
+        d = dqkv[sl].float().reshape(4, N, 3, D)
+        for i, nm in enumerate(["dQ", "dK", "dV"]):
+            ref = g[:, :, i]
+            _close(d[:, :, i], ref, 3e-2, 3e-2 * ref.abs().max().item(), f"{nm}, images {b0}..")
+            rel = ((d[:, :, i] - ref).norm() / ref.norm()).item()
+            worst[nm] = max(worst.get(nm, 0.0), rel)
+        del qr, o_ref, lse_ref, g
+    print("attention at B64 H6 N1569: worst relative L2 error per 4-image chunk", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert all(v <= 1e-2 for v in worst.values())
+
+
 def test_im2col(hip):
     from oracle import dichavit_oracle as orc
     B, Ct, H, P = 3, 6, 32, 8

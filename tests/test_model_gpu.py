@@ -197,6 +197,51 @@ def test_drop_path_parity(gpu_device):
             assert all(min(abs(v), abs(v - 1.0 / keep)) < 1e-5 for v in vals) and abs((t > 0).float().mean().item() - keep) < 0.04
 
 
+def test_gradient_accumulation_keeps_the_arena(gpu_device):
+    """the second and later backward passes of an optimiser step write into a scratch arena that autograd adds into .grad, so
+    .grad keeps aliasing model._grad_arena and HipAdamW / clip_grad_norm_ stay on their one-launch paths; the accumulated gradient equals
+    the sum of the single-pass gradients, and the fused update equals per-parameter updates."""
+    import diverse_channel_vit_amd as dcv
+    meta, _ = load_golden("so2sat_s")
+    batches = [orc.make_batch(900 + i, 4, 18, 32, 17) for i in range(3)]
+    ce = torch.nn.CrossEntropyLoss()
+
+    def run(model, idx):
+        for i in idx:
+            x, y = batches[i]
+            out, extra = model(x.to(gpu_device), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            (ce(out, y.to(gpu_device)) + extra).backward()
+
+    model, _ = build(meta, gpu_device)
+    model.stochastic_weight_rounding = False
+    run(model, [0, 1, 2])
+    ga = model._grad_arena
+    assert model._grad_scratch is not None
+    for p, o in zip(model._enc_params, model._enc_off):
+        assert p.grad is not None and p.grad.data_ptr() == ga.data_ptr() + 4 * o
+    acc = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    singles = None
+    for i in range(3):
+        m2, _ = build(meta, gpu_device)
+        m2.stochastic_weight_rounding = False
+        run(m2, [i])
+        g = {n: p.grad.detach().clone() for n, p in m2.named_parameters() if p.grad is not None}
+        singles = g if singles is None else {n: singles[n] + g[n] for n in g}
+    for n, g in acc.items():
+        assert (g - singles[n]).abs().max().item() <= 1e-5 * singles[n].abs().max().item() + 1e-9, n
+    # the optimiser sees arena-aliased gradients: one fused launch; compare with torch's AdamW on copies
+    ref_params = {n: p.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.04, model=model)
+    opt.step()
+    for n, p in model.named_parameters():
+        if n not in acc:
+            continue
+        q = torch.nn.Parameter(ref_params[n].clone())
+        q.grad = acc[n].clone()
+        torch.optim.AdamW([q], lr=1e-3, weight_decay=0.04).step()
+        assert (p.detach() - q.detach()).abs().max().item() <= 2e-6, n
+
+
 def test_hcs_subsets_parity(gpu_device):
     meta, a = load_golden("hcs")
     model, _ = build(meta, gpu_device)

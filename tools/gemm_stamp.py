@@ -28,7 +28,9 @@ for name, a, N, epi in cases:
     for it in range(6):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
-        hip.gemm_nt(a, W, epi, out, bias=bias, out2=out2, aux=aux, aux2=stamp.view(torch.float32), tile=tile)
+        sv = stamp.view(torch.float32)
+        hip.gemm_nt(a, W, epi, out, bias=bias, out2=sv if epi == hip.EPI_BIAS_RESID_F32 else out2, aux=aux,
+                    aux2=None if epi == hip.EPI_BIAS_RESID_F32 else sv, tile=tile)
         e.record(); torch.cuda.synchronize()
         ts.append(s.elapsed_time(e) * 1e3)
     st = stamp.view(256, 4).cpu().numpy().astype(np.float64)
