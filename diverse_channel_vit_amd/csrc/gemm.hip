@@ -373,11 +373,11 @@ __device__ __forceinline__ void nt_load_bias(const GemmNtArgs& a, int n_w, int r
 // Measured on MI355X (tools/ab_bench.py ablations, M = 100 416, K = 384):
 //   * the main loop alone sustains ~965 TFLOP/s: operands arrive by LDS-DMA, whole 128-byte lines (8 rows x 128 B per
 //     instruction), K streamed in 64-wide stages through a 3-deep ring (two 48 KB stages always in flight);
-//   * the epilogue costs as much again (N = 1152: 92 us loop + 63 us epilogue; fc1 + GELU: 122 + 166 us) because a CU
-//     issues stores at only ~14 B/clk and, with one 144 KB workgroup per CU, nothing else runs meanwhile.
+//   * the epilogue costs as much again (N = 1152: 92 us loop + 63 us epilogue; fc1 + GELU: 122 + 166 us): with every CU storing at
+//     once it runs at the HBM write rate (~5.3 TB/s chip-wide, profiles/r03_x8_*), and the board is at its power cap (r03_x6_*).
 // So the kernel is PERSISTENT: one workgroup per CU walks output tiles; after a tile's last stage it first issues the
-// auxiliary loads of its epilogue, then the NEXT tile's first two ring stages, and only then transposes / applies the
-// fused op / stores — from wave-private LDS slabs in the ring buffer that was consumed last, with no workgroup
+// auxiliary loads of its epilogue, then the NEXT tile's first two ring stages, and only then applies the fused op and stores —
+// straight from the accumulators (register epilogue above; rounds 1-2 went through wave-private LDS slabs), with no workgroup
 // barrier — so the store tail and the GELU arithmetic overlap the next tile's operand streaming.
 #ifndef DCV_TABL
 #define DCV_TABL 0  // gemm_tn timing-only ablations: 1 = no atomic epilogue, 2 = no MFMA / transposed reads
@@ -405,7 +405,7 @@ __device__ __forceinline__ void nt_load_bias(const GemmNtArgs& a, int n_w, int r
 #endif
 constexpr int NT_BM = 256, NT_BN = 128, NT_BK = 64, NT_STAGES = 3;
 constexpr int NT_A_BYTES = NT_BM * NT_BK * 2, NT_W_BYTES = NT_BN * NT_BK * 2, NT_STAGE_BYTES = NT_A_BYTES + NT_W_BYTES;  // 48 KB
-constexpr int NT_SMEM = NT_STAGES * NT_STAGE_BYTES;  // the ring (epilogue slabs alias the stage consumed last)
+constexpr int NT_SMEM = NT_STAGES * NT_STAGE_BYTES;  // the ring (the epilogue uses no LDS since round 3)
 
 // store instructions one wave issues in a full tile's epilogue (8 row-chunks of 8 columns per lane)
 template <int EPI>
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
                 if (dma_young) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            __builtin_amdgcn_s_barrier();  // everyone's stage g landed; everyone is done with buffer (g-1)%3 (reads and slabs)
+            __builtin_amdgcn_s_barrier();  // everyone's stage g landed; everyone is done reading buffer (g-1)%3
 #if DCV_DMA_SPLIT
             // The two waves of a SIMD (w and w + 4) issue their 6 DMA pieces at different times — one at the top of the stage, the
             // other between its two k-steps — so that one of them is always feeding the matrix pipe (a piece costs 60-180 issue cycles,
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
 // (256+384)*2 B per 256*384*2 FLOP = 154 FLOP/B, 1.8x fewer bytes per FLOP.  Cost: 192 accumulator registers per lane
 // (8 waves as 4 (M) x 2 (N), each 64 x 192 = 4 x 12 MFMA 16x16x32 tiles; the k-step's read / MFMA order is pinned, see the loop) and the
 // whole LDS: two 80 KB stages.  With two buffers the next stage is issued after the barrier that retires the previous
-// one, one k-iteration (48 MFMAs per wave) ahead.  Tile walk, slab epilogue and fused ops as in gemm_nt_kernel.
+// one, one k-iteration (48 MFMAs per wave) ahead.  Tile walk, register epilogue and fused ops as in gemm_nt_kernel.
 #if DCV_STAMP == 2
 // fine stamps (diagnostic build only): one statement = s_memtime + its wait, fenced for the scheduler (cdna guide, In-kernel stamps)
 __device__ __forceinline__ unsigned long long stamp_now() {
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
 #if DCV_STAMP == 2
             const unsigned long long f0b = stamp_now();
 #endif
-            __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done with buffer (g+1)&1 (reads / slabs)
+            __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done reading buffer (g+1)&1
 #if DCV_STAMP == 2
             const unsigned long long f1 = stamp_now();
 #endif
