@@ -89,3 +89,30 @@ def test_gemm_tile_choice_rules():
     assert tn(384, 1536) == W and tn(1536, 384) == W and tn(1152, 384) == W
     assert tn(384, 384) == N_ and tn(384, 256) == N_ and tn(200, 128) == N_
     assert tn(200, 128, W) < 0 and tn(384, 384, W) == W and tn(384, 1536, N_) == N_
+
+
+def test_deterministic_workspace_sizes_and_switch():
+    """The *_det_ws_floats entries are host logic (no GPU call): sizes for the headline step (256 CUs assumed without a device), and the
+    package-level switch that selects the deterministic forms (default on; the reference sets cudnn.deterministic = True)."""
+    import diverse_channel_vit_amd as dcv
+    from diverse_channel_vit_amd import hip
+    lib = hip.load()
+    M = 64 * 1569
+    # gemm_tn384: 256 CUs / 12 tiles = 21 splits of [P*Q] partial tiles + 21 x 3 rows of bias partials
+    assert lib.dcv_gemm_tn_det_ws_floats(M, 1536, 384, hip.TILE_AUTO) == 21 * 1536 * 384 + 21 * 3 * 1536
+    assert lib.dcv_gemm_tn_det_ws_floats(M, 384, 1536, hip.TILE_AUTO) == 21 * 384 * 1536 + 21 * 12 * 384
+XX
+    assert lib.dcv_gemm_tn_det_ws_floats(M, 384, 384, hip.TILE_AUTO) == 56 * (384 * 384 + 384)
+    assert lib.dcv_gemm_tn_det_ws_floats(10, 384, 384, hip.TILE_NARROW) == 1 * (384 * 384 + 384)  # fewer rows than a stage: one split
+    assert lib.dcv_gemm_tn_det_ws_floats(M, 200, 128, hip.TILE_WIDE) < 0                              # illegal forced tile
+    assert lib.dcv_ln_bwd_det_ws_floats(M, 384) == 1024 * 2 * 384 and lib.dcv_ln_bwd_det_ws_floats(10, 384) == 3 * 2 * 384
+    assert lib.dcv_patch_bwd_det_ws_floats(64, 8, 196, 384) == 98 * 2 * 8 * 384 + 8 * 2 * 196 * 384
+    assert lib.dcv_ortho_fwd_det_ws_floats(64, 8, 196, 384) == 7 * (64 * 8 * 384 + 64 * 8)
+    assert lib.dcv_sumsq_det_ws_floats(21_600_000) == 1024 and lib.dcv_sumsq_det_ws_floats(100) == 1
+    assert lib.dcv_ln_bwd_det_ws_floats(0, 384) < 0
+    old = dcv.set_deterministic(False)
+    try:
+        assert not dcv.is_deterministic()
+        assert dcv.set_deterministic(True) is False and dcv.is_deterministic()
+    finally:
+        dcv.set_deterministic(old)

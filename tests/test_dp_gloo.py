@@ -270,3 +270,43 @@ def test_evaluate_sums_counts_over_ranks_gloo_world2():
         p.join(60)
     for rank, acc in res:
         assert abs(acc - 100.0 * 7 / 16) < 1e-9
+
+
+def test_begin_forward_recovers_after_a_failed_backward():
+    """the autograd engine skips its end-of-backward callbacks when a backward pass raises, which used to leave the reducer's
+    `_callback_queued` flag set for good (no later pass would queue finalize()).  begin_forward() — called by the model at the start of every
+    training forward — clears the flag and the state the failed pass left behind."""
+    import torch.distributed as dist
+    from diverse_channel_vit_amd.dp import DataParallel
+
+    class Stub:
+        _dp = None
+
+        def parameters(self):
+            return []
+
+        def _enc_param_list(self):
+            return []
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        dp = DataParallel(Stub(), force_collectives=True)
+        t = torch.ones(8)
+        dp._callback_queued = True          # a backward queued the callback, then raised: the engine never ran it
+        dp._pending = (t, 0, 4)
+        dp._deferred = [t[:2]]
+
+        class W:
+            def wait(self):
+                raise RuntimeError("the failed pass's collective")
+
+        dp._works.append((W(), t, None))
+        dp.begin_forward()
+        assert not dp._callback_queued and dp._pending is None and not dp._deferred and not dp._works
+        dp.begin_forward()                  # a clean state is left alone
+        dp.grad_ready(t, 0, 8)
+        dp.finalize()
+        assert torch.equal(t, torch.ones(8))
+    finally:
+        dist.destroy_process_group()
