@@ -101,8 +101,9 @@ def test_deterministic_workspace_sizes_and_switch():
     # gemm_tn384: 256 CUs / 12 tiles = 21 splits of [P*Q] partial tiles + 21 x 3 rows of bias partials
     assert lib.dcv_gemm_tn_det_ws_floats(M, 1536, 384, hip.TILE_AUTO) == 21 * 1536 * 384 + 21 * 3 * 1536
     assert lib.dcv_gemm_tn_det_ws_floats(M, 384, 1536, hip.TILE_AUTO) == 21 * 384 * 1536 + 21 * 12 * 384
-XX
-    assert lib.dcv_gemm_tn_det_ws_floats(M, 384, 384, hip.TILE_AUTO) == 56 * (384 * 384 + 384)
+    # 128 x 128 kernel: 512 slots / 9 tiles = 56 splits asked for, 55 with rows once a split is a multiple of the 64-row stage
+    # (29 stages = 1856 rows each); the bias partial sits inside each split's slab
+    assert lib.dcv_gemm_tn_det_ws_floats(M, 384, 384, hip.TILE_AUTO) == 55 * (384 * 384 + 384)
     assert lib.dcv_gemm_tn_det_ws_floats(10, 384, 384, hip.TILE_NARROW) == 1 * (384 * 384 + 384)  # fewer rows than a stage: one split
     assert lib.dcv_gemm_tn_det_ws_floats(M, 200, 128, hip.TILE_WIDE) < 0                              # illegal forced tile
     assert lib.dcv_ln_bwd_det_ws_floats(M, 384) == 1024 * 2 * 384 and lib.dcv_ln_bwd_det_ws_floats(10, 384) == 3 * 2 * 384
