@@ -9,9 +9,32 @@ from diverse_channel_vit_amd import hip
 hip.load()
 
 
+def my_card_dirs():
+    """The sysfs device directory of the GPU this process computes on (several cards are visible on a shared host): matched by PCI address."""
+    bus = None
+    try:
+        import ctypes
+        torch.cuda.init()
+        hiprt = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hiprt.hipDeviceGetPCIBusId(buf, 64, torch.cuda.current_device()) == 0:
+            bus = buf.value.decode()  # e.g. "0000:75:00.0"
+    except Exception:
+        bus = None
+    dirs = []
+    for d in glob.glob("/sys/class/drm/card*/device"):
+        real = os.path.realpath(d)
+        if bus and os.path.basename(real).lower() == str(bus).lower():
+            dirs.append(d)
+    return dirs, bus
+
+
 def find_nodes():
     out = {}
-    for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+    dirs, bus = my_card_dirs()
+    pats = [d + "/hwmon/hwmon*" for d in dirs] or ["/sys/class/drm/card*/device/hwmon/hwmon*"]
+    out["_card"] = [f"pci {bus}: {dirs}" if dirs else f"pci {bus}: NOT matched, reading the maximum over all visible cards"]
+    for hw in (h for p in pats for h in glob.glob(p)):
         for key, name in (("power", "power1_average"), ("power_in", "power1_input"), ("cap", "power1_cap"), ("sclk", "freq1_input"), ("mclk", "freq2_input")):
             p = os.path.join(hw, name)
             if os.path.exists(p):
@@ -63,7 +86,8 @@ def run(name, fn, seconds=3.0):
     print(f"{name:44s} {us:8.1f} us/launch | power mean {np.nanmean(r[:, 0]):7.1f} W  max {np.nanmax(r[:, 0]):7.1f} W | sclk mean {np.nanmean(r[:, 1]):7.1f} MHz  min {np.nanmin(r[:, 1]):7.1f}", flush=True)
 
 
-print("nodes:", {k: v[:2] for k, v in NODES.items()})
+print("card:", NODES.get("_card"))
+print("nodes:", {k: v[:2] for k, v in NODES.items() if k != "_card"})
 for p in NODES.get("cap", []):
     print("power cap:", read(p) / 1e6, "W", p)
 M, D = 64 * 1569, 384
