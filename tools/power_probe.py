@@ -108,4 +108,15 @@ run("qkv GEMM wide, random operands", lambda: hip.gemm_nt(A, W, hip.EPI_BIAS_BF1
 run("qkv GEMM wide, ALL-ZERO operands", lambda: hip.gemm_nt(A0, W0, hip.EPI_BIAS_BF16, out, bias=bias, tile=hip.TILE_WIDE))
 run("qkv GEMM narrow, random operands", lambda: hip.gemm_nt(A, W, hip.EPI_BIAS_BF16, out, bias=bias, tile=hip.TILE_NARROW))
 run("attention forward B64 N1569 H6", lambda: hip.attn_fwd(qkv, o, lse, B, N, H, 64, 0.125))
+dO = torch.randn(B, N, D, device="cuda").to(bf); dqkv = torch.empty_like(qkv); ws = torch.empty(2, B, H, N, device="cuda")
+hip.attn_fwd(qkv, o, lse, B, N, H, 64, 0.125)
+lib = hip.load()
+import ctypes as C
+p_ = lambda t: C.c_void_p(t.data_ptr())
+st_ = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+run("attention backward dQ", lambda: lib.dcv_attn_bwd_dq_rows(p_(qkv), p_(o), p_(dO), p_(lse), p_(ws), p_(dqkv), B, N, N, H, 64, C.c_float(0.125), st_))
+run("attention backward dK/dV", lambda: lib.dcv_attn_bwd_dkdv_rows(p_(qkv), p_(dO), p_(lse), p_(ws), p_(dqkv), B, N, N, H, 64, C.c_float(0.125), st_))
+qz = torch.zeros_like(qkv); dz = torch.zeros_like(dO)
+run("attention backward dK/dV, ALL-ZERO operands", lambda: lib.dcv_attn_bwd_dkdv_rows(p_(qz), p_(dz), p_(lse), p_(ws), p_(dqkv), B, N, N, H, 64, C.c_float(0.125), st_))
+run("attention forward, ALL-ZERO operands", lambda: hip.attn_fwd(qz, o, lse, B, N, H, 64, 0.125))
 run("LayerNorm forward (HBM-bound)", lambda: hip.ln_fwd(x, g, b, u, mean, rstd, M, D, 1e-6))
