@@ -60,10 +60,14 @@ class DataParallel:
         return None
 
     def __init__(self, model, process_group=None, min_bucket_bytes: int = 4 << 20, force_collectives: bool = False,
-                 grad_dtype: torch.dtype = torch.float32, overlap: bool = True):
+                 grad_dtype: torch.dtype = torch.float32, overlap: bool = True, dist_module=None):
         """grad_dtype=torch.bfloat16 exchanges a bf16 copy of every bucket (43 MB instead of 86 MB per step for DiChaViT-S;
         the fp32 arena is overwritten with the averaged bf16 values).  overlap=False issues ONE all-reduce of everything
-        that became ready, after the backward (no collective runs beside the backward's kernels)."""
+        that became ready, after the backward (no collective runs beside the backward's kernels).
+        dist_module: the object the collectives are called on (default ``torch.distributed``); tests pass one that keeps RCCL's stream
+        semantics — asynchronous on a stream of its own, ordered after the issuing stream's position — on a box where RCCL cannot run
+        two ranks (tests/test_model_gpu.py, test_dp_async_collectives_emulated_on_one_gpu)."""
+        dist = self._dist = dist_module if dist_module is not None else globals()["dist"]
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         if grad_dtype not in (torch.float32, torch.bfloat16):
@@ -120,11 +124,11 @@ class DataParallel:
         if self.backend == "gloo" and buf.is_cuda:
             # gloo (tests on a one-GPU box) reduces host memory: stage through the CPU, synchronously
             h = buf.float().cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            self._dist.all_reduce(h, op=self._dist.ReduceOp.SUM, group=self.group)
             t.copy_(h.mul_(1.0 / self.world))
         else:
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            w = dist.all_reduce(buf, op=op, group=self.group, async_op=True)
+            op = self._dist.ReduceOp.AVG if self._avg else self._dist.ReduceOp.SUM
+            w = self._dist.all_reduce(buf, op=op, group=self.group, async_op=True)
             self._works.append((w, buf, dst))
         self.buckets_launched += 1
         self.bytes_reduced += buf.numel() * buf.element_size()
@@ -212,15 +216,15 @@ class DataParallel:
         if arena is not None:
             if self.backend == "gloo" and arena.is_cuda:
                 h = arena.cpu()
-                dist.broadcast(h, src=src, group=self.group)
+                self._dist.broadcast(h, src=src, group=self.group)
                 arena.copy_(h)
             else:
-                dist.broadcast(arena, src=src, group=self.group)
+                self._dist.broadcast(arena, src=src, group=self.group)
         else:
             for p in self.model.parameters():
                 if self.backend == "gloo" and p.is_cuda:
                     h = p.data.cpu()
-                    dist.broadcast(h, src=src, group=self.group)
+                    self._dist.broadcast(h, src=src, group=self.group)
                     p.data.copy_(h)
                 else:
-                    dist.broadcast(p.data, src=src, group=self.group)
+                    self._dist.broadcast(p.data, src=src, group=self.group)

@@ -1201,6 +1201,122 @@ def test_dp_two_ranks_rccl_two_gpus(gpu_device, grad_dtype, overlap):
             assert worst <= (2e-3 if grad_dtype == "float32" else 8e-3), worst
 
 
+class _EmulatedWork:
+    def __init__(self, done, dev, broken=False):
+        self.done, self.dev, self.broken = done, dev, broken
+
+    def wait(self):
+        if not self.broken:
+            torch.cuda.current_stream(self.dev).wait_event(self.done)  # what ProcessGroupNCCL's Work.wait() does: a stream wait, no host block
+        return True
+
+
+class _EmulatedRccl:
+    """Stands in for ``torch.distributed`` (DataParallel's dist_module) with RCCL's STREAM semantics, for one rank of a two-rank job on a
+    one-GPU box: every all-reduce runs asynchronously on a stream of its own, ordered after the issuing stream's position at the call
+    (an event recorded there), completes LATE (a spin kernel first), averages in place with what the peer rank contributed to the same
+    collective, and hands back a Work whose wait() is a stream wait.  peer=None: the recording pass of the peer rank (its k-th buffer is
+    copied on the collective's stream)."""
+
+    class ReduceOp:
+        SUM, AVG = "sum", "avg"
+
+    def __init__(self, dev, peer=None, delay_cycles=4_000_000, broken_wait=False):
+        self.dev, self.peer, self.delay, self.broken = dev, peer, delay_cycles, broken_wait
+        self.stream = torch.cuda.Stream(dev)
+        self.rec, self.k = [], 0
+
+    def is_initialized(self):
+        return True
+
+    def get_world_size(self, group=None):
+        return 2
+
+    def get_backend(self, group=None):
+        return "nccl"
+
+    def broadcast(self, t, src=0, group=None, async_op=False):
+        return None
+
+    def all_reduce(self, buf, op=None, group=None, async_op=False):
+        assert async_op and buf.is_cuda
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        buf.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            torch.cuda._sleep(self.delay)
+            if self.peer is None:
+                self.rec.append(buf.detach().clone())
+            else:
+                other = self.peer[self.k]
+                assert other.shape == buf.shape and other.dtype == buf.dtype, (self.k, other.shape, buf.shape)
+                buf.copy_((buf.float() + other.float()) * (0.5 if op == self.ReduceOp.AVG else 1.0))
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        self.k += 1
+        return _EmulatedWork(done, self.dev, self.broken)
+
+
+@pytest.mark.parametrize("grad_dtype,overlap", [("float32", True), ("bfloat16", True), ("float32", False)])
+def test_dp_async_collectives_emulated_on_one_gpu(gpu_device, grad_dtype, overlap):
+    """gloo is synchronous through the host and RCCL refuses two ranks on one device, so the ORDERING of the default
+    data-parallel backward — buckets handed over from the weight-gradient stream while the backward continues, the autograd engine's
+    end-of-backward callback as the only synchronisation — was never run against collectives that are really asynchronous and really
+    change the data.  Here they are (_EmulatedRccl): rank 1's contributions are recorded in a first pass, then rank 0 runs with
+    collectives that land late on their own stream.  The gradients are snapshotted ON THE COMPUTE STREAM straight after backward()
+    (no device synchronisation before: a consumer that did not wait would read un-averaged values) and must equal the single-process
+    sum over both ranks' batches / 2.  Control: the same run with a wait() that does nothing must FAIL that comparison."""
+    import diverse_channel_vit_amd as dcv
+    meta, _ = load_golden("tiny_e2e")
+    dev = gpu_device
+    ce = torch.nn.CrossEntropyLoss()
+    batches = {r: orc.make_batch(700 + r, 2, 3, 32, 5) for r in range(2)}
+
+    def one_rank(rank, comm):
+        model, _ = build(meta, dev)
+        model.stochastic_weight_rounding = False
+        dp = dcv.DataParallel(model, min_bucket_bytes=1 << 18, grad_dtype=getattr(torch, grad_dtype), overlap=overlap, dist_module=comm)
+        dp.hook_misc_params()
+        snaps = []
+        for step in range(2):  # the second step reuses the arena, the side stream and the events of the first
+            model.zero_grad(set_to_none=True)
+            x, y = batches[rank]
+            o, extra = model(x.to(dev), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            (ce(o, y.to(dev)) + extra).backward()
+            snaps.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})  # stream-ordered only
+        torch.cuda.synchronize()
+        return snaps, dp
+
+    rec = _EmulatedRccl(dev, peer=None)
+    one_rank(1, rec)
+    assert len(rec.rec) >= 2 * (2 if overlap else 1)
+
+    ref_model, _ = build(meta, dev)
+    ref_model.stochastic_weight_rounding = False
+    for r in range(2):
+        x, y = batches[r]
+        o, extra = ref_model(x.to(dev), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        (ce(o, y.to(dev)) + extra).backward()
+    torch.cuda.synchronize()
+    ref = {n: p.grad.detach().double() / 2 for n, p in ref_model.named_parameters() if p.grad is not None}
+
+    def worst_of(snap):
+        assert snap.keys() == ref.keys()
+        return max((snap[n].double() - ref[n]).norm().item() / (ref[n].norm().item() + 1e-30) for n in ref)
+
+    snaps, dp = one_rank(0, _EmulatedRccl(dev, peer=[t.clone() for t in rec.rec]))
+    assert dp.buckets_launched >= 2 * (2 if overlap else 1)
+    tol = 2e-3 if grad_dtype == "float32" else 8e-3
+    for step, snap in enumerate(snaps):
+        w = worst_of(snap)
+        print(f"emulated asynchronous collectives, step {step}: worst relative gradient difference vs single-process sum {w:.2e}")
+        assert w <= tol, (step, w)
+    # control: the test can see a missing wait
+    snaps_bad, _ = one_rank(0, _EmulatedRccl(dev, peer=[t.clone() for t in rec.rec], broken_wait=True))
+    assert worst_of(snaps_bad[0]) > 10 * tol, "a wait() that does nothing went unnoticed: the emulation has no teeth"
+
+
 def test_weight_gradients_on_second_stream_match_one_stream(gpu_device):
     """The backward runs the weight-gradient GEMMs on a second HIP stream (dichavit.py, _run_backward_body: wgrad_stream).  Same
     kernels on the same operands as the one-stream backward: every gradient must agree up to the order of the fp32 atomic adds of
