@@ -24,7 +24,7 @@ import math
 import os
 import random
 from collections import Counter, defaultdict
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch

@@ -1074,7 +1074,6 @@ def test_graph_replays_without_host_sync_follow_eager(gpu_device):
 
 def _two_rank_worker(rank, world, port, q, grad_dtype, overlap, backend="gloo"):
     import os
-    import sys
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     # gloo: both ranks on cuda:0 (RCCL refuses two ranks on one device); nccl (= RCCL): one GPU per rank, real asynchronous collectives
