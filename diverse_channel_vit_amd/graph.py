@@ -7,7 +7,7 @@ reads lr / weight decay / bias corrections from a device buffer that ``advance()
 schedulers and weight-decay schedules that edit ``param_groups[0]`` (trainer.py:1009-1019) keep working.
 
 Constraints (checked or documented): fixed input shape and channel subset (enable_sample=False, or a pinned
-``hcs_sampler``), single process (RCCL collectives are not captured: the multi-GPU path stays eager)."""
+``hcs_sampler``), DropPath masks from the device generator (torch.cuda.graph registers it: every replay draws new masks), single process (RCCL collectives are not captured: the multi-GPU path stays eager)."""
 from __future__ import annotations
 
 from typing import Callable, Optional
@@ -25,6 +25,9 @@ class GraphedTrainStep:
         if model.training and (model.cfg.get("dropout_tokens_hcs", "none") if hasattr(model.cfg, "get") else "none") not in (None, "none"):
             raise ValueError("dropout_tokens_hcs draws a new token subset every step from the python RNG: a captured step would "
                              "replay the subset drawn at capture time — run eager")
+        if model.training and getattr(model, "drop_path_sampler", None) is not None and any(r > 0 for r in model.feature_extractor.drop_path_rates):
+            raise ValueError("drop_path_sampler hands back host-made masks: a captured step would replay the masks of the capture — "
+                             "unset it (the default draw uses the device generator, which torch.cuda.graph advances per replay) or run eager")
         self.model, self.opt = model, optimizer
         self.chunk_name, self.training_chunks = chunk_name, training_chunks
         self.loss_fn = loss_fn or torch.nn.CrossEntropyLoss()
