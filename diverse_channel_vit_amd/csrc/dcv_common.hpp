@@ -214,7 +214,24 @@ static __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __r
 #pragma unroll
         for (int e = 0; e < W; ++e) s[e] = 0.f;
         const float* src = part + c;
-        for (int k = 0; k < nparts; ++k) {
+        int k = 0;
+        // eight parts' loads in flight, added in part order (a thread walking its parts one load at a time ran at ~2 TB/s)
+        for (; k + 8 <= nparts; k += 8) {
+            if constexpr (VEC) {
+                float4 t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(src + (size_t)(k + j) * part_stride);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[0] += t[j].x; s[1] += t[j].y; s[2] += t[j].z; s[3] += t[j].w; }
+            } else {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = src[(size_t)(k + j) * part_stride];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[0] += t[j];
+            }
+        }
+        for (; k < nparts; ++k) {
             if constexpr (VEC) {
                 const float4 t = *reinterpret_cast<const float4*>(src + (size_t)k * part_stride);
                 s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
@@ -228,23 +245,40 @@ static __global__ __launch_bounds__(256) void det_reduce_kernel(const float* __r
     }
 }
 // Same sum for MANY parts of FEW columns (LayerNorm: 1024 parts x 768 columns; one thread per column group would walk all parts alone):
-// a workgroup owns 16 column groups; part lane pl = thread / 16 adds parts pl, pl + 16, pl + 32, ... in increasing order, the 16 lane sums
-// are then added in lane order by the threads of lane 0.  The association order is fixed by (nparts) alone: deterministic.
+// a workgroup owns 4 column groups; part lane pl = thread / 4 adds parts pl, pl + 64, pl + 128, ... in increasing order (eight loads in flight),
+// the 64 lane sums are then added in lane order by the threads of lane 0.  The association order is fixed by (nparts) alone: deterministic.
+constexpr int DET_TALL_CG = 4, DET_TALL_PL = 256 / DET_TALL_CG;
 template <bool VEC>
 static __global__ __launch_bounds__(256) void det_reduce_tall_kernel(const float* __restrict__ part, int nparts, long part_stride,
                                                                      float* __restrict__ dstA, long nA, int QA, long ldA,
                                                                      float* __restrict__ dstB, long nB) {
     constexpr int W = VEC ? 4 : 1;
-    __shared__ float red[16][16][W];
-    const int pl = threadIdx.x >> 4, cg = threadIdx.x & 15;
+    __shared__ float red[DET_TALL_PL][DET_TALL_CG][W];
+    const int pl = threadIdx.x / DET_TALL_CG, cg = threadIdx.x % DET_TALL_CG;
     const long nv = (nA + nB) / W;
-    const long v = (long)blockIdx.x * 16 + cg;
+    const long v = (long)blockIdx.x * DET_TALL_CG + cg;
     float s[W];
 #pragma unroll
     for (int e = 0; e < W; ++e) s[e] = 0.f;
     if (v < nv) {
         const float* src = part + v * W;
-        for (int k = pl; k < nparts; k += 16) {
+        int k = pl;
+        for (; k + 7 * DET_TALL_PL < nparts; k += 8 * DET_TALL_PL) {
+            if constexpr (VEC) {
+                float4 t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float4*>(src + (size_t)(k + j * DET_TALL_PL) * part_stride);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[0] += t[j].x; s[1] += t[j].y; s[2] += t[j].z; s[3] += t[j].w; }
+            } else {
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = src[(size_t)(k + j * DET_TALL_PL) * part_stride];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[0] += t[j];
+            }
+        }
+        for (; k < nparts; k += DET_TALL_PL) {
             if constexpr (VEC) {
                 const float4 t = *reinterpret_cast<const float4*>(src + (size_t)k * part_stride);
                 s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
@@ -263,7 +297,7 @@ static __global__ __launch_bounds__(256) void det_reduce_tall_kernel(const float
         for (int e = 0; e < W; ++e) {
             float t = 0.f;
 #pragma unroll
-            for (int l = 0; l < 16; ++l) t += red[l][cg][e];
+            for (int l = 0; l < DET_TALL_PL; ++l) t += red[l][cg][e];
             d[e] += t;
         }
     }
@@ -275,7 +309,7 @@ static inline bool det_reduce(const float* part, int nparts, long part_stride, f
                      !((uintptr_t)dstA & 15) && !((uintptr_t)dstB & 15);
     const long nv = (nA + nB) / (vec ? 4 : 1);
     if (nparts >= 32 && nv <= 16384) {  // many parts, few columns
-        const unsigned grid = (unsigned)((nv + 15) / 16);
+        const unsigned grid = (unsigned)((nv + DET_TALL_CG - 1) / DET_TALL_CG);
         if (vec) hipLaunchKernelGGL(det_reduce_tall_kernel<true>, dim3(grid), dim3(256), 0, s, part, nparts, part_stride, dstA, nA, QA, ldA, dstB, nB);
         else hipLaunchKernelGGL(det_reduce_tall_kernel<false>, dim3(grid), dim3(256), 0, s, part, nparts, part_stride, dstA, nA, QA, ldA, dstB, nB);
         return hipGetLastError() == hipSuccess;
