@@ -1251,9 +1251,11 @@ class _EmulatedRccl:
     class ReduceOp:
         SUM, AVG = "sum", "avg"
 
-    def __init__(self, dev, peer=None, delay_cycles=4_000_000, broken_wait=False):
+    def __init__(self, dev, peer=None, delay_cycles=12_000_000, broken_wait=False):  # ~5 ms per collective on this clock
         self.dev, self.peer, self.delay, self.broken = dev, peer, delay_cycles, broken_wait
-        self.stream = torch.cuda.Stream(dev)
+        # high priority: HIP maps streams onto a few hardware queues, and a collective stream that shares its queue with the compute stream
+        # would run in enqueue order with it — nothing would be asynchronous and the missing-wait control would pass for the wrong reason
+        self.stream = torch.cuda.Stream(dev, priority=-1)
         self.rec, self.k = [], 0
 
     def is_initialized(self):
@@ -1274,15 +1276,23 @@ class _EmulatedRccl:
         ev.record(torch.cuda.current_stream(self.dev))
         buf.record_stream(self.stream)
         with torch.cuda.stream(self.stream):
-            self.stream.wait_event(ev)
-            torch.cuda._sleep(self.delay)
+            # every allocation BEFORE the spin kernel: one behind it may reach hipMalloc, which synchronises the device — the host would
+            # sit out the delay and the late collective would no longer be late (the missing-wait control then fails to fail)
             if self.peer is None:
-                self.rec.append(buf.detach().clone())
+                keep = torch.empty_like(buf)
             else:
                 other = self.peer[self.k]
                 assert other.shape == buf.shape and other.dtype == buf.dtype, (self.k, other.shape, buf.shape)
-                buf.copy_((buf.float() + other.float()) * (0.5 if op == self.ReduceOp.AVG else 1.0))
+                other32, tmp = other.float(), torch.empty(buf.shape, dtype=torch.float32, device=buf.device)
             done = torch.cuda.Event()
+            self.stream.wait_event(ev)
+            torch.cuda._sleep(self.delay)
+            if self.peer is None:
+                self.rec.append(keep.copy_(buf.detach()))
+            else:
+                tmp.copy_(buf)
+                tmp.add_(other32).mul_(0.5 if op == self.ReduceOp.AVG else 1.0)
+                buf.copy_(tmp)
             done.record(self.stream)
         self.k += 1
         return _EmulatedWork(done, self.dev, self.broken)
@@ -1309,12 +1319,19 @@ def test_dp_async_collectives_emulated_on_one_gpu(gpu_device, grad_dtype, overla
         dp = dcv.DataParallel(model, min_bucket_bytes=1 << 18, grad_dtype=getattr(torch, grad_dtype), overlap=overlap, dist_module=comm)
         dp.hook_misc_params()
         snaps = []
+        x, y = batches[rank][0].to(dev), batches[rank][1].to(dev)
         for step in range(2):  # the second step reuses the arena, the side stream and the events of the first
             model.zero_grad(set_to_none=True)
-            x, y = batches[rank]
-            o, extra = model(x.to(dev), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
-            (ce(o, y.to(dev)) + extra).backward()
-            snaps.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})  # stream-ordered only
+            # snapshot buffers exist BEFORE the backward: an allocation after it may reach hipMalloc, which synchronises the device and
+            # would hide a missing wait (the control below failed to fail for exactly that reason once)
+            bufs = {n: torch.empty_like(p) for n, p in model.named_parameters()}
+            o, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            (ce(o, y) + extra).backward()
+            snap = {}
+            for n, p in model.named_parameters():
+                if p.grad is not None:
+                    snap[n] = bufs[n].copy_(p.grad.detach())  # stream-ordered only
+            snaps.append(snap)
         torch.cuda.synchronize()
         return snaps, dp
 
