@@ -251,6 +251,7 @@ class DiChaViT(nn.Module):
         self._grad_scratch = None
         self._dp = None  # set by diverse_channel_vit_amd.dp.DataParallel
         self.wgrad_stream = True  # the backward runs the weight-gradient GEMMs on a second HIP stream (_run_backward_body); False: one stream
+        self.wgrad_private_scratch = os.environ.get("DCV_WGRAD_PRIVATE", "1") != "0"  # per-layer scratch instead of reader waits (_run_backward_body)
         self._side = None
         self._R_cache: Dict = {}
         self._idx_cache: Dict = {}
@@ -776,6 +777,11 @@ class DiChaViT(nn.Module):
                 readers.clear()
 
         dxb_alt = None
+        # wgrad_private_scratch: every layer gets scratch of its own for the buffers the second stream reads (dz, dqkv, dxb: 0.7 GB per layer at
+        # the headline shape, held until the join below; the allocator recycles them step to step), so the compute stream never has to wait for
+        # a reader before it overwrites one.  Those waits were always satisfied long before, but each is a barrier packet in the compute
+        # queue (4 per layer) and cost ~8 us of queue time: 36.58 -> 36.23 ms per step, same bits (profiles/r03_x12_*).
+        private = side_all is not None and self.wgrad_private_scratch
         for li in range(len(fe.blocks) - 1, -1, -1):
             blk, L = fe.blocks[li], st["layers"][li]
             tail = L["tail"]
@@ -785,14 +791,23 @@ class DiChaViT(nn.Module):
             R = B if tail else M
             dz_, du_ = (dz[:R], du[:R]) if tail else (dz, du)
             # MLP
-            before_write("dz")
+            if private and side is not None:
+                held.append(dz)
+                dz = torch.empty_like(dz)
+                dz_ = dz
+            else:
+                before_write("dz")
             hip.gemm_nt(dxb, self._bf(blk.mlp.fc2.weight, True), hip.EPI_GELU_BWD_BF16, dz_, aux=L["z"], **nt_kw)
             wgrad(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias), id(dxb))
             hip.gemm_nt(dz_, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du_, **nt_kw)
             wgrad(dz_, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias), "dz")
-            if side is not None:
-                dxb, dxb_alt = dxb_alt, dxb  # the fc2 weight gradient may still be reading the old one
-            before_write(id(dxb))
+            if private and side is not None:
+                held.append(dxb)
+                dxb = torch.empty_like(dxb)
+            else:
+                if side is not None:
+                    dxb, dxb_alt = dxb_alt, dxb  # the fc2 weight gradient may still be reading the old one
+                before_write(id(dxb))
             dsc = L.get("drop")  # this block's (attention, MLP) DropPath factors: the copy written here feeds its attention branch
             hip.ln_bwd(du_, L["x_mid"], L["mean2"], L["rstd2"], blk.norm2.weight, dx, dx, dxb, g(blk.norm2.weight), g(blk.norm2.bias), R, D,
                        **(dict(bf16_row_scale=dsc[0], rows_per_sample=R // B) if dsc else {}))
@@ -810,13 +825,21 @@ class DiChaViT(nn.Module):
             else:
                 hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO, **nt_kw)
                 wgrad(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias), id(dxb))
-                before_write("dqkv")
+                if private:
+                    held.append(dqkv)
+                    dqkv = torch.empty_like(dqkv)
+                else:
+                    before_write("dqkv")
                 hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
             hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du, **nt_kw)
             wgrad(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv")
-            if side is not None:
-                dxb, dxb_alt = dxb_alt, dxb
-            before_write(id(dxb))
+            if private and side is not None:
+                held.append(dxb)
+                dxb = torch.empty_like(dxb)
+            else:
+                if side is not None:
+                    dxb, dxb_alt = dxb_alt, dxb
+                before_write(id(dxb))
             below = st["layers"][li - 1].get("drop") if li > 0 else None  # the copy written here feeds the MLP branch of the block below
             hip.ln_bwd(du, L["x_in"], L["mean1"], L["rstd1"], blk.norm1.weight, dx, dx, dxb, g(blk.norm1.weight), g(blk.norm1.bias), M, D,
                        **(dict(bf16_row_scale=below[1], rows_per_sample=N) if below else {}))

@@ -86,3 +86,15 @@ if len(sys.argv) > 2:  # list the launches of one region in order: "list" = the 
     for s_, e_, n_ in seg:
         if s_ >= a and s_ < b:
             print(f"    {1e-3 * (s_ - a):8.1f} {1e-3 * (e_ - s_):6.1f}  {short(n_)}")
+
+# gap statistics by the pair (kernel that ended, kernel that started next), for pairs seen at least 5 times
+pairs = collections.defaultdict(list)
+ends = sorted((e, n) for s_, e, n in seg)
+for (s0, e0), (s1, e1) in zip(busy, busy[1:]):
+    nxt = starts[bisect.bisect_right(starts, e0)] if bisect.bisect_right(starts, e0) < len(starts) else None
+    pairs[(short(by_end.get(e0, "?"))[:28], short(by_start.get(nxt, "?"))[:28])].append(s1 - e0)
+print("  idle time between the end of one kernel and the start of the next, by pair (count, median us):")
+for k, v in sorted(pairs.items(), key=lambda kv: -sum(kv[1])):
+    if len(v) >= 5:
+        v = sorted(v)
+        print(f"    {len(v):3d} x {v[len(v) // 2] / 1e3:5.1f} us   {k[0]:28s} -> {k[1]}")
