@@ -6,7 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 libs = sys.argv[1:] or [os.path.join(ROOT, "diverse_channel_vit_amd", "libdcv_hip.so")]
 hs = [C.CDLL(l) for l in libs]
-M, D = 64 * 1569, 384
+M, D = int(os.environ.get("TB_M", 64 * 1569)), 384  # TB_M: token rows (small M: the operands stay in the 256 MB memory-side cache between launches)
 bf = torch.bfloat16
 torch.manual_seed(0)
 T = {d: torch.randn(M, d, device="cuda").to(bf) for d in (384, 1152, 1536)}
@@ -26,4 +26,4 @@ for (P, Q) in [(1536, 384), (384, 1536), (1152, 384), (384, 384)]:
             assert rc == 0
             if rnd >= 2:
                 res[i].append(s.elapsed_time(e) * 1e3 / 3)
-    print(f"P{P} Q{Q}: " + "  ".join(f"{os.path.basename(libs[i])} {np.median(v):7.1f} (min {min(v):7.1f})" for i, v in res.items()), flush=True)
+    print(f"M{M} P{P} Q{Q}: " + "  ".join(f"{os.path.basename(libs[i])} {np.median(v):7.1f} (min {min(v):7.1f})" for i, v in res.items()), flush=True)
