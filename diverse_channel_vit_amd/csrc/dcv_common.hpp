@@ -302,6 +302,58 @@ static __global__ __launch_bounds__(256) void det_reduce_tall_kernel(const float
         }
     }
 }
+// Several of those sums in ONE launch (the grouped weight-gradient GEMM: up to 8 products x (weight, bias) = 16 jobs, each a few microseconds
+// of work behind a launch): workgroup b belongs to the job j with wg_start[j] <= b < wg_start[j + 1]; inside a job exactly det_reduce_kernel<true>.
+constexpr int DET_MULTI_MAX = 16;
+struct DetJobs {
+    int n;
+    int wg_start[DET_MULTI_MAX + 1];
+    const float* part[DET_MULTI_MAX];
+    int nparts[DET_MULTI_MAX];
+    long stride[DET_MULTI_MAX];
+    float* dst[DET_MULTI_MAX];
+    long nv[DET_MULTI_MAX];  // float4 columns
+    int Q[DET_MULTI_MAX];
+    long ld[DET_MULTI_MAX];
+};
+static __global__ __launch_bounds__(256) void det_reduce_multi_kernel(DetJobs jb) {
+    int j = 0;
+    while (j + 1 < jb.n && (int)blockIdx.x >= jb.wg_start[j + 1]) ++j;
+    const long v = (long)((int)blockIdx.x - jb.wg_start[j]) * 256 + threadIdx.x;
+    if (v >= jb.nv[j]) return;
+    const long c = v * 4;
+    const float* src = jb.part[j] + c;
+    const long stride = jb.stride[j];
+    const int nparts = jb.nparts[j];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 8 <= nparts; k += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = *reinterpret_cast<const float4*>(src + (size_t)(k + i) * stride);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s0 += t[i].x; s1 += t[i].y; s2 += t[i].z; s3 += t[i].w; }
+    }
+    for (; k < nparts; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(src + (size_t)k * stride);
+        s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
+    }
+    float* d = jb.dst[j] + (c / jb.Q[j]) * jb.ld[j] + (c % jb.Q[j]);
+    d[0] += s0; d[1] += s1; d[2] += s2; d[3] += s3;
+}
+// adds job (part, nparts, stride) -> dst[(c / Q) * ld + c % Q], c < n, to jb; false when the job does not fit the vector form or the table
+static inline bool det_jobs_add(DetJobs& jb, const float* part, int nparts, long stride, float* dst, long n, int Q, long ld) {
+    if (jb.n >= DET_MULTI_MAX || (n & 3) || (Q & 3) || (ld & 3) || (stride & 3) || ((uintptr_t)part & 15) || ((uintptr_t)dst & 15)) return false;
+    const int j = jb.n++;
+    jb.part[j] = part; jb.nparts[j] = nparts; jb.stride[j] = stride; jb.dst[j] = dst; jb.nv[j] = n / 4; jb.Q[j] = Q; jb.ld[j] = ld;
+    jb.wg_start[j + 1] = jb.wg_start[j] + (int)((n / 4 + 255) / 256);
+    return true;
+}
+static inline bool det_reduce_multi(const DetJobs& jb, hipStream_t s) {
+    if (jb.n <= 0) return true;
+    hipLaunchKernelGGL(det_reduce_multi_kernel, dim3((unsigned)jb.wg_start[jb.n]), dim3(256), 0, s, jb);
+    return hipGetLastError() == hipSuccess;
+}
 // launches the reduction; returns false when the launch failed
 static inline bool det_reduce(const float* part, int nparts, long part_stride, float* dstA, long nA, int QA, long ldA, float* dstB, long nB,
                               hipStream_t s) {

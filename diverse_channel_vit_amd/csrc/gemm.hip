@@ -1032,14 +1032,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 #endif
 constexpr int T3_BK = 32, T3_STAGES = DCV_T3_STAGES, T3_IMG = T3_BK * 256, T3_STAGE_BYTES = 4 * T3_IMG;  // 8 KB images, 32 KB stages
 
-__global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
+// bid: the workgroup's logical id inside this product, in [0, tiles * splits), tile index fastest
+__device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid) {
     __shared__ __attribute__((aligned(16))) char smem[T3_STAGES * T3_STAGE_BYTES];  // 128 KB: one workgroup per CU
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave >> 1, wq = wave & 1;
     const int h = lane >> 5, r32 = lane & 31, li = lane & 15, g1 = (lane >> 4) & 1;
     const int tiles_q = a.Q / 128, tiles = tiles_q * (a.P / 384);
-    int bid = xcd_remap(blockIdx.x, tiles * a.splits);
     const int split = bid / tiles;
     bid -= split * tiles;
     const int tq = bid % tiles_q, tp = bid / tiles_q;
@@ -1194,6 +1194,27 @@ __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
             else atomicAdd(a.dbias + p0 + tid, sum);
         }
     }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
+    tn384_body(a, xcd_remap(blockIdx.x, (a.Q / 128) * (a.P / 384) * a.splits));
+}
+
+// Several weight-gradient products over the SAME token rows in one launch (a block's fc2 / fc1 / proj / qkv gradients: 36 tiles).  The CUs are
+// filled by the tiles of all of them, so each tile is split 7 ways over the rows instead of 21 (or 85 for the 384 x 384 product): a third of
+// the partial-tile traffic, k-loops three times as long, one launch and one fixed cost (~40 us of flush per launch, tools/tn_bench.py) instead of four.
+constexpr int TN_GROUP_MAX = 8;
+struct GemmTnGroup {
+    int n;
+    int start[TN_GROUP_MAX + 1];  // logical ids [start[i], start[i + 1]) belong to item i
+    GemmTnArgs d[TN_GROUP_MAX];
+};
+__global__ __launch_bounds__(512) void gemm_tn384_group_kernel(GemmTnGroup g) {
+    const int id = xcd_remap(blockIdx.x, g.start[g.n]);
+    int i = 0;
+    while (i + 1 < g.n && id >= g.start[i + 1]) ++i;
+    const GemmTnArgs a = g.d[i];
+    tn384_body(a, id - g.start[i]);
 }
 
 }  // namespace
@@ -1393,6 +1414,80 @@ extern "C" int dcv_gemm_tn_acc_det(const void* Y, int ldy, const void* X, int ld
                                    float* dbias, int tile, float* ws, long ws_floats, void* stream) {
     if (!ws) return DCV_ERR_NULL;
     return tn_launch(Y, ldy, X, ldx, M, P, Q, dW, lddw, dbias, tile, ws, ws_floats, stream);
+}
+
+// ---- grouped form (include/dcv.h: dcv_tn_item) --------------------------------------------------------------------------------------------
+static int tn_group_plan(const dcv_tn_item* it, int n, int M, int cus, int& splits, int& mps, long* off, long& need) {
+    if (!it) return DCV_ERR_NULL;
+    if (n < 1 || n > TN_GROUP_MAX || M <= 0) return DCV_ERR_SHAPE;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!it[i].Y || !it[i].X || !it[i].dW) return DCV_ERR_NULL;
+        if (it[i].P <= 0 || it[i].Q <= 0 || (it[i].P % 384) || (it[i].Q % 128)) return DCV_ERR_UNSUPPORTED;
+        if ((it[i].ldy % 8) || (it[i].ldx % 8) || ((uintptr_t)it[i].Y & 15) || ((uintptr_t)it[i].X & 15)) return DCV_ERR_ALIGN;
+        tiles += (it[i].P / 384) * (it[i].Q / 128);
+    }
+    if (tiles > cus) return DCV_ERR_UNSUPPORTED;  // more than one resident round: call the products one by one
+    splits = cus / tiles;
+    const int max3 = (M + T3_BK - 1) / T3_BK;
+    if (splits > max3) splits = max3;
+    mps = ((M + splits - 1) / splits + T3_BK - 1) / T3_BK * T3_BK;
+    splits = (M + mps - 1) / mps;
+    need = 0;
+    for (int i = 0; i < n; ++i) {  // per item: [splits][P * Q] partial tiles, then [splits * tiles_q][P] bias partials
+        off[i] = need;
+        need += (long)splits * it[i].P * it[i].Q + (long)splits * (it[i].Q / 128) * it[i].P;
+    }
+    return DCV_OK;
+}
+
+extern "C" long dcv_gemm_tn_group_ws_floats(const dcv_tn_item* items, int n, int M) {
+    int splits, mps;
+    long off[TN_GROUP_MAX], need;
+    const int rc = tn_group_plan(items, n, M, dcv_cu_count(), splits, mps, off, need);
+    return rc ? rc : need;
+}
+
+extern "C" int dcv_gemm_tn_group(const dcv_tn_item* items, int n, int M, float* ws, long ws_floats, void* stream) {
+    int splits, mps;
+    long off[TN_GROUP_MAX], need;
+    const int rc = tn_group_plan(items, n, M, dcv_cu_count(), splits, mps, off, need);
+    if (rc) return rc;
+    if (ws) {
+        if ((uintptr_t)ws & 15) return DCV_ERR_ALIGN;
+        if (ws_floats < need) return DCV_ERR_SHAPE;
+        for (int i = 0; i < n; ++i)
+            if ((items[i].lddw % 4) || ((uintptr_t)items[i].dW & 15) || (items[i].dbias && ((uintptr_t)items[i].dbias & 15))) return DCV_ERR_ALIGN;
+    }
+    GemmTnGroup g;
+    g.n = n;
+    int id = 0;
+    for (int i = 0; i < n; ++i) {
+        const dcv_tn_item& t = items[i];
+        g.start[i] = id;
+        id += (t.P / 384) * (t.Q / 128) * splits;
+        const long stride = (long)t.P * t.Q;
+        g.d[i] = GemmTnArgs{(const bf16_t*)t.Y, t.ldy, (const bf16_t*)t.X, t.ldx, M, t.P, t.Q, t.dW, t.lddw, t.dbias, mps, splits,
+                            ws ? ws + off[i] : nullptr, stride, stride * splits};
+    }
+    g.start[n] = id;
+    for (int i = n + 1; i <= TN_GROUP_MAX; ++i) g.start[i] = id;
+    hipLaunchKernelGGL(gemm_tn384_group_kernel, dim3(id), dim3(512), 0, (hipStream_t)stream, g);
+    DCV_LAUNCH_CHECK();
+    if (ws) {  // the fixed-order second pass of every product (weight, bias) in one launch
+        DetJobs jb;
+        jb.n = 0;
+        jb.wg_start[0] = 0;
+        for (int i = 0; i < n; ++i) {
+            const dcv_tn_item& t = items[i];
+            const long stride = (long)t.P * t.Q;
+            float* w = ws + off[i];
+            if (!det_jobs_add(jb, w, splits, stride, t.dW, stride, t.Q, t.lddw)) return DCV_ERR_ALIGN;
+            if (t.dbias && !det_jobs_add(jb, w + stride * splits, splits * (t.Q / 128), t.P, t.dbias, t.P, t.P, t.P)) return DCV_ERR_ALIGN;
+        }
+        if (!det_reduce_multi(jb, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
+    }
+    return DCV_OK;
 }
 
 extern "C" int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw,

@@ -252,6 +252,8 @@ class DiChaViT(nn.Module):
         self._dp = None  # set by diverse_channel_vit_amd.dp.DataParallel
         self.wgrad_stream = True  # the backward runs the weight-gradient GEMMs on a second HIP stream (_run_backward_body); False: one stream
         self.wgrad_private_scratch = os.environ.get("DCV_WGRAD_PRIVATE", "1") != "0"  # per-layer scratch instead of reader waits (_run_backward_body)
+        self.wgrad_group = os.environ.get("DCV_WGRAD_GROUP", "1") != "0"  # a block's four weight gradients in one launch (needs the private scratch)
+        self._group_cache = {}
         self._side = None
         self._R_cache: Dict = {}
         self._idx_cache: Dict = {}
@@ -764,6 +766,25 @@ class DiChaViT(nn.Module):
                 done.record(side)
             readers[key] = done
 
+        # wgrad_group (with private scratch): a block's four weight-gradient products go out as ONE launch (dcv_gemm_tn_group) once the last of
+        # their operands (dqkv) exists: the tiles of all four fill the CUs, so each is split 7 ways over the token rows instead of 21-85 ways
+        grp = []
+
+        def wgrad_or_collect(Y, X, gw, gb, key, grouped):
+            if grouped:
+                grp.append((Y, X, gw, gb))
+            else:
+                wgrad(Y, X, gw, gb, key)
+
+        def launch_group():
+            items = list(grp)
+            grp.clear()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                hip.gemm_tn_acc_group(items)
+
         def before_write(key):
             ev = readers.pop(key, None)
             if ev is not None:
@@ -790,6 +811,7 @@ class DiChaViT(nn.Module):
                 dxb_alt = torch.empty_like(dxb)
             R = B if tail else M
             dz_, du_ = (dz[:R], du[:R]) if tail else (dz, du)
+            grouped = bool(private and side is not None and self.wgrad_group and self._group_ok(M, D))
             # MLP
             if private and side is not None:
                 held.append(dz)
@@ -798,9 +820,9 @@ class DiChaViT(nn.Module):
             else:
                 before_write("dz")
             hip.gemm_nt(dxb, self._bf(blk.mlp.fc2.weight, True), hip.EPI_GELU_BWD_BF16, dz_, aux=L["z"], **nt_kw)
-            wgrad(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias), id(dxb))
+            wgrad_or_collect(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias), id(dxb), grouped)
             hip.gemm_nt(dz_, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du_, **nt_kw)
-            wgrad(dz_, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias), "dz")
+            wgrad_or_collect(dz_, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias), "dz", grouped)
             if private and side is not None:
                 held.append(dxb)
                 dxb = torch.empty_like(dxb)
@@ -824,7 +846,7 @@ class DiChaViT(nn.Module):
                 dxb = torch.empty(M, D, dtype=bf, device=dev)
             else:
                 hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO, **nt_kw)
-                wgrad(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias), id(dxb))
+                wgrad_or_collect(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias), id(dxb), grouped)
                 if private:
                     held.append(dqkv)
                     dqkv = torch.empty_like(dqkv)
@@ -832,7 +854,9 @@ class DiChaViT(nn.Module):
                     before_write("dqkv")
                 hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
             hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du, **nt_kw)
-            wgrad(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv")
+            wgrad_or_collect(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv", grouped)
+            if grouped:
+                launch_group()
             if private and side is not None:
                 held.append(dxb)
                 dxb = torch.empty_like(dxb)
@@ -884,6 +908,14 @@ class DiChaViT(nn.Module):
         for p in self._enc_params:
             grads.append(self._gview(ga, p) if p.requires_grad else None)
         return dE, dpos, grads
+
+    def _group_ok(self, M, D):
+        """Does dcv_gemm_tn_group take a block's four weight-gradient products (fc2, fc1, proj, qkv) in one launch on this device?"""
+        key = (M, D)
+        ok = self._group_cache.get(key)
+        if ok is None:
+            ok = self._group_cache[key] = hip.gemm_tn_group_supported([(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)], M)
+        return ok
 
     def _side_stream(self, dev):
         if self._side is None or self._side.device != dev:

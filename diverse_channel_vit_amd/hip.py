@@ -27,6 +27,8 @@ _SIGS = {
     "dcv_gemm_tn_acc_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp], _i),
     "dcv_gemm_tn_det_ws_floats": ([_i, _i, _i, _i], _l),
     "dcv_gemm_tn_acc_det": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _l, _vp], _i),
+    "dcv_gemm_tn_group_ws_floats": ([_vp, _i, _i], _l),
+    "dcv_gemm_tn_group": ([_vp, _i, _i, _vp, _l, _vp], _i),
     "dcv_ln_fwd": ([_vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp], _i),
     "dcv_ln_bwd": ([_vp, _i, _vp, _l, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _vp, _i, _i, _vp], _i),
     "dcv_ln_bwd_det_ws_floats": ([_i, _i], _l),
@@ -228,6 +230,51 @@ def gemm_tn_det_ws_floats(M, P, Q, tile=TILE_AUTO) -> int:
     if n < 0:
         _check(int(n), "dcv_gemm_tn_det_ws_floats")
     return int(n)
+
+
+class _TnItem(C.Structure):  # include/dcv.h: dcv_tn_item
+    _fields_ = [("Y", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("dbias", C.c_void_p),
+                ("ldy", C.c_int), ("ldx", C.c_int), ("P", C.c_int), ("Q", C.c_int), ("lddw", C.c_int), ("reserved", C.c_int)]
+
+
+def gemm_tn_group_supported(shapes, M) -> bool:
+    """shapes: iterable of (P, Q).  True when dcv_gemm_tn_group takes them in one launch on this device (every P % 384 == 0, Q % 128 == 0,
+    all tiles in one resident round)."""
+    shapes = list(shapes)
+    if not 1 <= len(shapes) <= 8:
+        return False
+    arr = (_TnItem * len(shapes))()
+    for it, (P, Q) in zip(arr, shapes):
+        it.Y = it.X = it.dW = 16  # non-null, aligned placeholders: the size query reads shapes only
+        it.ldy, it.ldx, it.P, it.Q, it.lddw = P, Q, P, Q, Q
+    return load().dcv_gemm_tn_group_ws_floats(C.cast(arr, C.c_void_p), len(shapes), M) >= 0
+
+
+def gemm_tn_acc_group(items):
+    """items: list of (Y [M,P] bf16, X [M,Q] bf16, dW [P,Q] f32, dbias [P] f32 or None) over the SAME M rows: every dW += Y^T X and dbias +=
+    colsum(Y) in ONE launch (dcv_gemm_tn_group); deterministic mode takes the partial tiles through the per-stream workspace."""
+    lib = load()
+    n = len(items)
+    arr = (_TnItem * n)()
+    M = items[0][0].shape[0]
+    flops = 0.0
+    nbytes = 0.0
+    for it, (Y, X, dW, db) in zip(arr, items):
+        _req(Y, torch.bfloat16, "Y"); _req(X, torch.bfloat16, "X"); _req(dW, torch.float32, "dW")
+        if Y.shape[0] != M or X.shape[0] != M or dW.shape != (Y.shape[1], X.shape[1]):
+            raise ValueError("gemm_tn_acc_group: every item is (Y [M,P], X [M,Q], dW [P,Q]) over the same M")
+        it.Y, it.X, it.dW, it.dbias = Y.data_ptr(), X.data_ptr(), dW.data_ptr(), (db.data_ptr() if db is not None else None)
+        it.ldy, it.ldx, it.P, it.Q, it.lddw = Y.stride(0), X.stride(0), Y.shape[1], X.shape[1], dW.stride(0)
+        flops += 2.0 * M * Y.shape[1] * X.shape[1]
+        nbytes += 2.0 * M * (Y.shape[1] + X.shape[1]) + 8.0 * Y.shape[1] * X.shape[1]
+    ptr = C.cast(arr, C.c_void_p)
+    ws = None
+    if _deterministic:
+        ws = _workspace(_ws_size(lib.dcv_gemm_tn_group_ws_floats(ptr, n, M)), items[0][2])
+    shape = f"M{M} " + "+".join(f"{it.P}x{it.Q}" for it in arr)
+    with _timer(lambda: ("gemm_tn384_group_kernel", shape, flops, flops, nbytes)):
+        rc = lib.dcv_gemm_tn_group(ptr, n, M, _p(ws), ws.numel() if ws is not None else 0, _stream())
+    _check(rc, "dcv_gemm_tn_group")
 
 
 def gemm_tn_acc(Y, X, dW, dbias=None, tile=TILE_AUTO, ws=None):

@@ -75,6 +75,23 @@ long dcv_gemm_tn_det_ws_floats(int M, int P, int Q, int tile);
 int dcv_gemm_tn_acc_det(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias,
                         int tile, float* ws, long ws_floats, void* stream);
 
+/* Several weight-gradient products over the SAME M token rows in ONE launch (round 3): dW_i[P_i,Q_i] += Y_i[M,P_i]^T X_i[M,Q_i],
+ * dbias_i[P_i] += colsum(Y_i) (dbias may be NULL) for i < n <= 8.  Every P_i % 384 == 0 and Q_i % 128 == 0 and the tiles of all products
+ * together must fit one resident round (sum of (P_i/384)(Q_i/128) <= CUs), else DCV_ERR_UNSUPPORTED: call the products one by one.  The CUs
+ * are filled by the tiles of all products, so each tile is split far fewer ways over the rows than in n separate launches (a block's four
+ * gradients: 7 ways instead of 21 / 21 / 28 / 85): a third of the partial-tile traffic and one launch's fixed cost instead of four.
+ * ws != NULL: the deterministic form (dcv_gemm_tn_group_ws_floats(items, n, M) floats; partial tiles through ws, fixed-order second pass);
+ * ws == NULL: fp32 atomics.  Replaces the four torch.autograd weight-gradient GEMMs of Block.backward (models/vit.py:72-82, 116-142). */
+typedef struct dcv_tn_item {
+    const void* Y; /* bf16 [M, P], row stride ldy */
+    const void* X; /* bf16 [M, Q], row stride ldx */
+    float* dW;     /* fp32 [P, Q], row stride lddw, accumulated into */
+    float* dbias;  /* fp32 [P] or NULL */
+    int ldy, ldx, P, Q, lddw, reserved;
+} dcv_tn_item;
+long dcv_gemm_tn_group_ws_floats(const dcv_tn_item* items, int n, int M);
+int dcv_gemm_tn_group(const dcv_tn_item* items, int n, int M, float* ws, long ws_floats, void* stream);
+
 /* LayerNorm (eps inside the sqrt, biased variance) — vit.py:361,374 / dichavit.py:651.
  * out is bf16 [M,D] (or f32 when out_is_f32); mean/rstd [M] may be NULL. x rows are x_row_stride floats apart. */
 int dcv_ln_fwd(const float* x, long x_row_stride, const float* gamma, const float* beta, void* out, int out_is_f32, float* mean,
