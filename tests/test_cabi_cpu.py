@@ -111,6 +111,18 @@ def test_deterministic_workspace_sizes_and_switch():
     assert lib.dcv_ortho_fwd_det_ws_floats(64, 8, 196, 384) == 7 * (64 * 8 * 384 + 64 * 8)
     assert lib.dcv_sumsq_det_ws_floats(21_600_000) == 1024 and lib.dcv_sumsq_det_ws_floats(100) == 1
     assert lib.dcv_ln_bwd_det_ws_floats(0, 384) < 0
+    # grouped weight gradients of one block: 12 + 12 + 3 + 9 = 36 tiles -> 256 / 36 = 7 splits for every product
+    D = 384
+    shapes = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)]
+    arr = (hip._TnItem * 4)()
+    for it, (P, Q) in zip(arr, shapes):
+        it.Y = it.X = it.dW = 16
+        it.ldy, it.ldx, it.P, it.Q, it.lddw = P, Q, P, Q, Q
+    import ctypes as C
+    want = sum(7 * P * Q + 7 * (Q // 128) * P for P, Q in shapes)
+    assert lib.dcv_gemm_tn_group_ws_floats(C.cast(arr, C.c_void_p), 4, M) == want
+    assert hip.gemm_tn_group_supported(shapes, M) and not hip.gemm_tn_group_supported([(100, 128)], M)
+    assert not hip.gemm_tn_group_supported([(4 * D, 4 * D)] * 8, M) and not hip.gemm_tn_group_supported([], M)
     old = dcv.set_deterministic(False)
     try:
         assert not dcv.is_deterministic()

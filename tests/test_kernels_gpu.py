@@ -221,6 +221,48 @@ def test_gemm_tn_deterministic(hip, M, P, Q, tile):
         hip.gemm_tn_acc(Y, X, dW, db, tile=t, ws=ws[: max(nws // 2, 4)])
 
 
+@pytest.mark.parametrize("M", [64 * 197 + 5, 31, 5000])
+def test_gemm_tn_group(hip, M, reduction_mode):
+    """dcv_gemm_tn_group: a block's four weight-gradient products (fc2, fc1, proj, qkv shapes) over the same token rows in ONE launch, both
+    reduction modes, accumulating into non-zero dW / dbias (one of them without a bias): against the fp32 product, against four separate
+    dcv_gemm_tn_acc launches, bit-identical from run to run in deterministic mode; ragged and shorter-than-a-stage reductions; shapes the
+    grouped form does not take are reported, not computed."""
+    D = 384
+    shapes = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)]
+    assert hip.gemm_tn_group_supported(shapes, M)
+    ops = [(_bf(M, P, seed=20 + i, scale=0.3), _bf(M, Q, seed=30 + i)) for i, (P, Q) in enumerate(shapes)]
+
+    def fresh():
+        g = torch.Generator(device="cuda").manual_seed(5)
+        return [(torch.randn(P, Q, device="cuda", generator=g), (torch.randn(P, device="cuda", generator=g) if i != 2 else None))
+                for i, (P, Q) in enumerate(shapes)]
+
+    init = fresh()
+    runs = []
+    for rep in range(3 if reduction_mode == "det" else 1):
+        outs = fresh()
+        hip.gemm_tn_acc_group([(Y, X, dW, db) for (Y, X), (dW, db) in zip(ops, outs)])
+        runs.append(outs)
+    sep = fresh()
+    for (Y, X), (dW, db) in zip(ops, sep):
+        hip.gemm_tn_acc(Y, X, dW, db)
+    for i, ((Y, X), (dW, db), (dW0, db0), (dWs, dbs)) in enumerate(zip(ops, runs[0], init, sep)):
+        ref = dW0.double() + Y.double().T @ X.double()
+        assert ((dW.double() - ref).norm() / ref.norm()).item() < 2e-6, i
+        assert ((dW - dWs).norm() / dWs.norm()).item() < 2e-6, i
+        if db is None:
+            continue
+        rb = db0.double() + Y.double().sum(0)
+        assert ((db.double() - rb).norm() / rb.norm()).item() < 2e-6, i
+    if reduction_mode == "det":
+        for other in runs[1:]:
+            assert all(torch.equal(a[0], b[0]) and (a[1] is None or torch.equal(a[1], b[1])) for a, b in zip(runs[0], other))
+    assert not hip.gemm_tn_group_supported([(D, 4 * D), (100, D)], M)          # P not a multiple of 384
+    assert not hip.gemm_tn_group_supported([(4 * D, 4 * D)] * 8, M)             # 8 x 48 tiles: more than one resident round
+    with pytest.raises(RuntimeError):
+        hip.gemm_tn_acc_group([(_bf(M, 256, seed=1), _bf(M, 128, seed=2), torch.zeros(256, 128, device="cuda"), None)])
+
+
 @pytest.mark.parametrize("M", [31, 32, 33, 1000, 4099])
 def test_gemm_tn_wide_ragged_reduction(hip, M):
     """384 x 128 kernel with reduction lengths around its 32-row stage (ragged last stage, fewer stages than the ring is deep)."""
