@@ -119,4 +119,11 @@ run("attention backward dK/dV", lambda: lib.dcv_attn_bwd_dkdv_rows(p_(qkv), p_(d
 qz = torch.zeros_like(qkv); dz = torch.zeros_like(dO)
 run("attention backward dK/dV, ALL-ZERO operands", lambda: lib.dcv_attn_bwd_dkdv_rows(p_(qz), p_(dz), p_(lse), p_(ws), p_(dqkv), B, N, N, H, 64, C.c_float(0.125), st_))
 run("attention forward, ALL-ZERO operands", lambda: hip.attn_fwd(qz, o, lse, B, N, H, 64, 0.125))
+gq = lambda m, n, sc=1.0: (torch.randn(m, n, device="cuda") * sc).to(bf)
+tn_ops = [(gq(M, D, 0.1), gq(M, 4 * D)), (gq(M, 4 * D, 0.1), gq(M, D)), (gq(M, D, 0.1), gq(M, D)), (gq(M, 3 * D, 0.1), gq(M, D))]
+tn_out = [(torch.zeros(Y.shape[1], X.shape[1], device="cuda"), torch.zeros(Y.shape[1], device="cuda")) for Y, X in tn_ops]
+run("weight gradients of a block, one grouped launch", lambda: hip.gemm_tn_acc_group([(Y, X, dW, db) for (Y, X), (dW, db) in zip(tn_ops, tn_out)]))
+tn_zero = [(torch.zeros_like(Y), torch.zeros_like(X)) for Y, X in tn_ops]
+run("the same on ALL-ZERO operands", lambda: hip.gemm_tn_acc_group([(Y, X, dW, db) for (Y, X), (dW, db) in zip(tn_zero, tn_out)]))
+run("weight gradient fc1 alone (P1536 Q384)", lambda: hip.gemm_tn_acc(tn_ops[1][0], tn_ops[1][1], tn_out[1][0], tn_out[1][1]))
 run("LayerNorm forward (HBM-bound)", lambda: hip.ln_fwd(x, g, b, u, mean, rstd, M, D, 1e-6))
