@@ -779,6 +779,9 @@ class DiChaViT(nn.Module):
         def launch_group():
             items = list(grp)
             grp.clear()
+            if side is None:  # one stream
+                hip.gemm_tn_acc_group(items)
+                return
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
@@ -802,7 +805,7 @@ class DiChaViT(nn.Module):
         # the headline shape, held until the join below; the allocator recycles them step to step), so the compute stream never has to wait for
         # a reader before it overwrites one.  Those waits were always satisfied long before, but each is a barrier packet in the compute
         # queue (4 per layer) and cost ~8 us of queue time: 36.58 -> 36.23 ms per step, same bits (profiles/r03_x12_*).
-        private = side_all is not None and self.wgrad_private_scratch
+        private = bool(self.wgrad_private_scratch)  # on one stream too: the grouped weight-gradient launch below needs its operands alive
         for li in range(len(fe.blocks) - 1, -1, -1):
             blk, L = fe.blocks[li], st["layers"][li]
             tail = L["tail"]
@@ -811,9 +814,10 @@ class DiChaViT(nn.Module):
                 dxb_alt = torch.empty_like(dxb)
             R = B if tail else M
             dz_, du_ = (dz[:R], du[:R]) if tail else (dz, du)
-            grouped = bool(private and side is not None and self.wgrad_group and self._group_ok(M, D))
+            priv = private and not tail
+            grouped = bool(priv and self.wgrad_group and self._group_ok(M, D))
             # MLP
-            if private and side is not None:
+            if priv:
                 held.append(dz)
                 dz = torch.empty_like(dz)
                 dz_ = dz
@@ -823,7 +827,7 @@ class DiChaViT(nn.Module):
             wgrad_or_collect(dxb, L["h"], g(blk.mlp.fc2.weight), g(blk.mlp.fc2.bias), id(dxb), grouped)
             hip.gemm_nt(dz_, self._bf(blk.mlp.fc1.weight, True), hip.EPI_PLAIN_BF16, du_, **nt_kw)
             wgrad_or_collect(dz_, L["u2"], g(blk.mlp.fc1.weight), g(blk.mlp.fc1.bias), "dz", grouped)
-            if private and side is not None:
+            if priv:
                 held.append(dxb)
                 dxb = torch.empty_like(dxb)
             else:
@@ -847,7 +851,7 @@ class DiChaViT(nn.Module):
             else:
                 hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO, **nt_kw)
                 wgrad_or_collect(dxb, L["o"], g(blk.attn.proj.weight), g(blk.attn.proj.bias), id(dxb), grouped)
-                if private:
+                if priv:
                     held.append(dqkv)
                     dqkv = torch.empty_like(dqkv)
                 else:
@@ -857,7 +861,7 @@ class DiChaViT(nn.Module):
             wgrad_or_collect(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv", grouped)
             if grouped:
                 launch_group()
-            if private and side is not None:
+            if priv:
                 held.append(dxb)
                 dxb = torch.empty_like(dxb)
             else:
