@@ -448,6 +448,7 @@ def main():
                        "host_syncs_per_step": 0,
                        "launch": "hip-graph replay of the captured step" if use_graph else "eager",
                        "wgrad_stream": bool(model.wgrad_stream),
+                       "wgrad_group": bool(model.wgrad_group and model.wgrad_private_scratch),  # a block's four weight gradients in one launch
                        "reductions": ("deterministic: partial sums through workspaces, fixed-order second pass (bit-reproducible gradients)"
                                       if hip.is_deterministic() else "fp32 atomics (order-dependent in the last bits; --atomic-reductions)"),
                        **({"hcs": "enable_sample lowest_cosine_prob temp 1000 (E[C] = 4.5 of 8 channels; img/s counts whole images)",
