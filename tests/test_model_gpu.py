@@ -1364,6 +1364,32 @@ def test_dp_async_collectives_emulated_on_one_gpu(gpu_device, grad_dtype, overla
     assert worst_of(snaps_bad[0]) > 10 * tol, "a wait() that does nothing went unnoticed: the emulation has no teeth"
 
 
+@pytest.mark.parametrize("private,group,two_streams", [(False, False, True), (True, False, True), (False, False, False), (True, True, False)])
+def test_backward_scratch_and_grouping_fallbacks(gpu_device, private, group, two_streams):
+    """The backward's switches (dichavit.py, _run_backward_body): per-layer scratch or two shared buffers with reader waits, a block's four weight
+    gradients in one grouped launch or in four, one stream or two.  Every combination is the same arithmetic up to the split of the weight-gradient
+    sums over the token rows: the gradients must agree with the default configuration's (private scratch, grouped, two streams) to fp32 rounding."""
+    meta, a = load_golden("so2sat_s")
+    x, y = orc.make_batch(meta["seed"] + 1, meta["B"], meta["C_in"], meta["img"], meta["num_classes"])
+    grads = {}
+    for cfg in ("default", "variant"):
+        model, _ = build(meta, gpu_device)
+        model.stochastic_weight_rounding = False
+        if cfg == "variant":
+            model.wgrad_private_scratch, model.wgrad_group, model.wgrad_stream = private, group, two_streams
+        for _ in range(2):  # a second pass reuses the scratch the first one left in the allocator
+            model.zero_grad(set_to_none=True)
+            out, extra = model(x.to(gpu_device), meta["chunk"], None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            (torch.nn.CrossEntropyLoss()(out, y.to(gpu_device)) + extra).backward()
+        torch.cuda.synchronize()
+        grads[cfg] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert grads["default"].keys() == grads["variant"].keys()
+    for n, g in grads["variant"].items():
+        ref = grads["default"][n]
+        err = (g - ref).abs().max().item()
+        assert err <= 1e-5 * ref.abs().max().item() + 1e-9, (n, err, ref.abs().max().item())
+
+
 def test_weight_gradients_on_second_stream_match_one_stream(gpu_device):
     """The backward runs the weight-gradient GEMMs on a second HIP stream (dichavit.py, _run_backward_body: wgrad_stream).  Same
     kernels on the same operands as the one-stream backward: every gradient must agree up to the order of the fp32 atomic adds of
