@@ -698,7 +698,7 @@ class DiChaViT(nn.Module):
         # once.  Both are explicit arguments of dcv_gemm_nt_ex; the forward, where nothing else runs, keeps the wide tiles and
         # the full grid.
         nt_kw = {}
-        if dp is not None and (dp.world > 1 or dp._force):
+        if dp is not None and (dp.world > 1 or dp._force) and dp.overlap:  # overlap=False: no collective runs beside the backward, nothing to make room for
             cus = torch.cuda.get_device_properties(dfeat.device).multi_processor_count if dfeat.is_cuda else 256
             nt_kw = dict(grid_cap=max(cus - dp.reserved_cus, 1), tile=hip.TILE_NARROW)
         if dp is not None:

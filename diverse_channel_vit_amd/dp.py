@@ -199,16 +199,47 @@ class DataParallel:
         self.flush()
         if self._deferred:
             ts, self._deferred = self._deferred, []
-            # one collective over everything that became ready (contiguous arena slices are coalesced by torch)
-            flat = torch.cat([t.reshape(-1) for t in ts]) if len(ts) > 1 else ts[0].reshape(-1)
-            self._all_reduce(flat)
-            self._wait_all()
-            if len(ts) > 1:
-                o = 0
-                for t in ts:
-                    t.copy_(flat[o:o + t.numel()].view_as(t))
-                    o += t.numel()
+            # The encoder's slices are views of ONE arena and arrive last layer first: neighbours are merged into a single view and reduced
+            # in place (no gather, no copy back: 2 x 86 MB of traffic per step for DiChaViT-S otherwise); what does not merge (the few small
+            # parameters outside the arena) travels as one concatenated buffer.
+            merged, loose = self._merge_views(ts)
+            for m in merged:
+                self._all_reduce(m)
+            if loose:
+                flat = torch.cat([t.reshape(-1) for t in loose]) if len(loose) > 1 else loose[0].reshape(-1)
+                self._all_reduce(flat)
+                self._wait_all()
+                if len(loose) > 1:
+                    o = 0
+                    for t in loose:
+                        t.copy_(flat[o:o + t.numel()].view_as(t))
+                        o += t.numel()
         self._wait_all()
+
+    @staticmethod
+    def _merge_views(ts):
+        """Splits `ts` into (merged, loose): 1-D contiguous views of a common base whose element ranges touch are replaced by one view over
+        their union (in address order); everything else is returned unchanged in `loose`."""
+        groups, loose = {}, []
+        for t in ts:
+            base = t._base
+            if base is None or t.dim() != 1 or not t.is_contiguous() or not base.is_contiguous() or base.dtype != t.dtype:
+                loose.append(t)
+            else:
+                groups.setdefault(id(base), (base, []))[1].append((t.storage_offset() - base.storage_offset(), t.numel()))
+        merged = []
+        for base, spans in groups.values():
+            spans.sort()
+            flat = base.view(-1)
+            lo, hi = spans[0][0], spans[0][0] + spans[0][1]
+            for o, n in spans[1:]:
+                if o <= hi:
+                    hi = max(hi, o + n)
+                else:
+                    merged.append(flat[lo:hi])
+                    lo, hi = o, o + n
+            merged.append(flat[lo:hi])
+        return merged, loose
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Same initial weights on every rank (DDP does this in its constructor)."""
