@@ -310,3 +310,20 @@ def test_begin_forward_recovers_after_a_failed_backward():
         assert torch.equal(t, torch.ones(8))
     finally:
         dist.destroy_process_group()
+
+
+def test_merge_views_of_one_arena():
+    """DataParallel._merge_views (overlap=False): neighbouring 1-D views of one arena become ONE view over their union, whatever order they
+    arrive in; views that do not touch stay separate; tensors that are not contiguous 1-D views of a base are returned as they are."""
+    from diverse_channel_vit_amd.dp import DataParallel
+    arena = torch.arange(100, dtype=torch.float32)
+    other = torch.zeros(5)
+    ts = [arena[60:80], arena[40:60], arena[10:20], other, arena[80:100], torch.ones(2, 3).t()[0]]  # the last one: a strided view
+    merged, loose = DataParallel._merge_views(ts)
+    spans = sorted((int(m[0].item()), m.numel()) for m in merged)
+    assert spans == [(10, 10), (40, 60)]
+    assert all(m.data_ptr() == arena.data_ptr() + 4 * int(m[0].item()) for m in merged)  # views, not copies
+    assert len(loose) == 2 and loose[0] is other and not loose[1].is_contiguous()
+    merged[1 if merged[0].numel() == 10 else 0].mul_(0)  # writing the merged view writes the arena
+    assert float(arena[40:100].abs().sum()) == 0.0 and float(arena[10:20].sum()) == sum(range(10, 20))
+
