@@ -20,6 +20,7 @@ Design (MI355X-first, not a translation):
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import random
@@ -776,17 +777,16 @@ class DiChaViT(nn.Module):
             else:
                 wgrad(Y, X, gw, gb, key)
 
-        def launch_group():
+        def launch_group(plan):
             items = list(grp)
             grp.clear()
-            if side is None:  # one stream
-                hip.gemm_tn_acc_group(items)
-                return
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                hip.gemm_tn_acc_group(items)
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                for members in plan:  # one launch per group of the plan (_group_ok)
+                    hip.gemm_tn_acc_group([items[i] for i in members])
 
         def before_write(key):
             ev = readers.pop(key, None)
@@ -815,7 +815,8 @@ class DiChaViT(nn.Module):
             R = B if tail else M
             dz_, du_ = (dz[:R], du[:R]) if tail else (dz, du)
             priv = private and not tail
-            grouped = bool(priv and self.wgrad_group and self._group_ok(M, D))
+            plan = self._group_ok(M, D) if (priv and self.wgrad_group) else ()
+            grouped = bool(plan)
             # MLP
             if priv:
                 held.append(dz)
@@ -860,7 +861,7 @@ class DiChaViT(nn.Module):
             hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du, **nt_kw)
             wgrad_or_collect(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv", grouped)
             if grouped:
-                launch_group()
+                launch_group(plan)
             if priv:
                 held.append(dxb)
                 dxb = torch.empty_like(dxb)
@@ -914,12 +915,30 @@ class DiChaViT(nn.Module):
         return dE, dpos, grads
 
     def _group_ok(self, M, D):
-        """Does dcv_gemm_tn_group take a block's four weight-gradient products (fc2, fc1, proj, qkv) in one launch on this device?"""
+        """How a block's four weight-gradient products (in the order the backward produces their operands: fc2, fc1, proj, qkv) are grouped
+        into dcv_gemm_tn_group launches on this device: a tuple of index tuples, or () when they should go out one by one.  A group's tiles
+        (384 x 128) times the splits they leave room for (CUs // tiles) should fill the chip: DiChaViT-S has 36 tiles -> one group of 7 splits
+        (252 of 256 CUs); DiChaViT-B has 144 -> one group would leave 44 % of the CUs idle, (fc2, proj) + (fc1, qkv) fill 94 % and 98 %."""
         key = (M, D)
-        ok = self._group_cache.get(key)
-        if ok is None:
-            ok = self._group_cache[key] = hip.gemm_tn_group_supported([(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)], M)
-        return ok
+        plan = self._group_cache.get(key)
+        if plan is None:
+            shapes = [(D, 4 * D), (4 * D, D), (D, D), (3 * D, D)]
+            cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
+            tiles = [(P // 384) * (Q // 128) if (P % 384 == 0 and Q % 128 == 0) else None for P, Q in shapes]
+
+            def fill(group):
+                t = sum(tiles[i] for i in group)
+                return (t * (cus // t)) / cus if 0 < t <= cus else 0.0
+
+            plan = ()
+            if all(t is not None for t in tiles):
+                parts = [((0, 1, 2, 3),), ((0, 2), (1, 3)), ((0, 1), (2, 3)), ((0, 3), (1, 2)), ((0,), (1, 2, 3)), ((1,), (0, 2, 3)), ((2,), (0, 1, 3)),
+                         ((3,), (0, 1, 2))]
+                best = max(parts, key=lambda pt: (min(fill(g_) for g_ in pt) >= 0.9, -len(pt), min(fill(g_) for g_ in pt)))
+                if min(fill(g_) for g_ in best) >= 0.9 and all(hip.gemm_tn_group_supported([shapes[i] for i in g_], M) for g_ in best):
+                    plan = best
+            self._group_cache[key] = plan
+        return plan
 
     def _side_stream(self, dev):
         if self._side is None or self._side.device != dev:
