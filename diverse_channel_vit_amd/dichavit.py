@@ -223,6 +223,26 @@ class _EncoderFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None, dE, dpos) + tuple(grads)
 
 
+class _ChannelProxyLossFn(torch.autograd.Function):
+    """proxy_loss(proxies, channel_embed, eye(C), scale) (models/loss_fn.py:7-21 as dichavit.py:399-402 calls it) with the value and both
+    gradients from ONE kernel launch (dcv_proxy_loss); the backward scales the saved gradients by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, proxies, emb, scale):
+        proxies, emb = proxies.contiguous(), emb.contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=emb.device)
+        grads = torch.empty(2, *emb.shape, dtype=torch.float32, device=emb.device)
+        hip.proxy_loss(emb, proxies, scale, out, grads[0], grads[1])
+        ctx.save_for_backward(grads)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, = ctx.saved_tensors
+        gg = grads * g
+        return gg[1], gg[0], None
+
+
 class DiChaViT(nn.Module):
     def __init__(self, config, **kwargs):
         super().__init__()
@@ -253,6 +273,7 @@ class DiChaViT(nn.Module):
         self._dp = None  # set by diverse_channel_vit_amd.dp.DataParallel
         self.wgrad_stream = True  # the backward runs the weight-gradient GEMMs on a second HIP stream (_run_backward_body); False: one stream
         self.wgrad_private_scratch = os.environ.get("DCV_WGRAD_PRIVATE", "1") != "0"  # per-layer scratch instead of reader waits (_run_backward_body)
+        self.fused_proxy_loss = os.environ.get("DCV_FUSED_PROXY_LOSS", "1") != "0"  # the channel-embedding proxy term as one kernel (dcv_proxy_loss)
         self.wgrad_group = os.environ.get("DCV_WGRAD_GROUP", "1") != "0"  # a block's four weight gradients in one launch (needs the private scratch)
         self._group_cache = {}
         self._side = None
@@ -1021,12 +1042,16 @@ class DiChaViT(nn.Module):
         if lam_p > 0 and (self.training or True):
             # the reference evaluates the proxy term in eval mode too and discards it; skip it there
             if self.training:
-                prox = pe.channel_emb_proxies[self._index_tensor(cur_channels, torch.int64, x.device)]  # global ids (:401)
-                extra = extra + lam_p * _proxy_loss(prox, channel_embed, torch.eye(C, device=x.device), float(pe.channel_scale))
+                prox = pe.channel_emb_proxies.index_select(0, self._index_tensor(cur_channels, torch.int64, x.device))  # global ids (:401)
+                if (self.fused_proxy_loss and prox.dtype == torch.float32 and channel_embed.dtype == torch.float32
+                        and hip.proxy_loss_supported(C, self.dim)):
+                    extra = extra + lam_p * _ChannelProxyLossFn.apply(prox, channel_embed, float(pe.channel_scale))
+                else:
+                    extra = extra + lam_p * _proxy_loss(prox, channel_embed, torch.eye(C, device=x.device), float(pe.channel_scale))
         out = self.classifer_head(feat)  # :855
         if self.training:
             if isinstance(extra, int) and extra == 0:
-                extra = torch.tensor(0.0, device=out.device)  # :857-858
+                extra = out.new_zeros(())  # :857-858 (a device-side fill: torch.tensor(0.0, device=...) is a synchronising host-to-device copy)
             return out, extra
         return out
 

@@ -55,6 +55,8 @@ _SIGS = {
     "dcv_fill_cls": ([_vp, _vp, _vp, _i, _l, _i, _vp], _i),
     "dcv_ortho_fwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_ortho_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
+    "dcv_proxy_loss_supported": ([_i, _i], _i),
+    "dcv_proxy_loss": ([_vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp], _i),
     "dcv_adamw": ([_vp, _vp, _vp, _vp, _l, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
     "dcv_adamw_dyn": ([_vp, _vp, _vp, _vp, _l, _vp, _vp], _i),
     "dcv_adamw_set_hyper": ([_vp, _f, _f, _f, _f, _f, _i, _f, _vp], _i),
@@ -433,3 +435,17 @@ def cast_bf16_sr(src, dst, n, seed_dev):
 def cast_transpose_bf16_sr(src_base, dst_base, desc_dev, n_desc, max_tiles, seed_dev):
     _check(load().dcv_cast_transpose_bf16_sr(_p(src_base), _p(dst_base), _p(desc_dev), n_desc, max_tiles, _p(seed_dev), _stream()),
            "dcv_cast_transpose_bf16_sr")
+
+
+def proxy_loss_supported(C: int, D: int) -> bool:
+    return bool(load().dcv_proxy_loss_supported(C, D))
+
+
+def proxy_loss(emb, proxies, scale: float, loss, d_emb, d_proxies):
+    """loss[0] = CE(-cdist(scale * normalize(emb), scale * normalize(proxies))^2, eye(C)); d_emb / d_proxies = its gradients (dcv_proxy_loss)."""
+    _req(emb, torch.float32, "emb"); _req(proxies, torch.float32, "proxies")
+    C_, D_ = emb.shape
+    if proxies.shape != emb.shape or not emb.is_contiguous() or not proxies.is_contiguous():
+        raise ValueError("proxy_loss: emb and proxies are contiguous [C, D] fp32 tensors of the same shape")
+    _check(load().dcv_proxy_loss(_p(emb), _p(proxies), C_, D_, float(scale), _p(loss), _p(d_emb), _p(d_proxies), _stream()), "dcv_proxy_loss")
+

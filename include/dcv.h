@@ -175,6 +175,14 @@ int dcv_ortho_fwd(const float* Y, float* S, float* selfsq, float* tot, float* in
 int dcv_ortho_bwd(const float* Y, const float* S, const float* tot, const float* inv_norm, const float* coef, float* dY, int B,
                   int C, int n, int D, void* stream);
 
+/* The channel-embedding proxy regulariser in ONE launch, value and both gradients (round 3): emb [C, D] and proxies [C, D] fp32 contiguous;
+ * loss[0] = cross_entropy(-cdist(scale * normalize(emb), scale * normalize(proxies))^2, eye(C)) (mean over rows), d_emb / d_proxies [C, D] =
+ * its gradients (for an upstream gradient of 1).  Replaces proxy_loss(channel_emb_proxies[cur_channels], channel_embed, eye, scale)
+ * (models/dichavit.py:399-402, models/loss_fn.py:7-21) and its autograd backward: ~40 launches on [C, D] tensors.  dcv_proxy_loss_supported:
+ * C <= 32, D <= 1024, C * D <= 16384 (two normalised copies in LDS); DCV_ERR_UNSUPPORTED otherwise (the caller keeps the op-by-op form). */
+int dcv_proxy_loss_supported(int C, int D);
+int dcv_proxy_loss(const float* emb, const float* proxies, int C, int D, float scale, float* loss, float* d_emb, float* d_proxies, void* stream);
+
 /* fused AdamW over a flat fp32 range; g is multiplied by grad_scale first (1/world for data parallel). */
 int dcv_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
               float weight_decay, int step, float grad_scale, void* stream);

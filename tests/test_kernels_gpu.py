@@ -221,6 +221,41 @@ def test_gemm_tn_deterministic(hip, M, P, Q, tile):
         hip.gemm_tn_acc(Y, X, dW, db, tile=t, ws=ws[: max(nws // 2, 4)])
 
 
+@pytest.mark.parametrize("C,D", [(8, 384), (3, 384), (18, 384), (16, 768), (1, 192), (32, 512)])
+def test_proxy_loss_kernel(hip, C, D):
+    """dcv_proxy_loss: value and both gradients of cross_entropy(-cdist(s * normalize(e), s * normalize(p))^2, eye(C)) in one launch, against
+    autograd on the reference's own formula (models/loss_fn.py:7-21) in float64 — also with a zero row (normalize clamps the norm at 1e-12)
+    and with nearly parallel rows (large logits); sizes beyond the kernel's LDS budget are refused."""
+    import torch.nn.functional as F
+    scale = float(np.sqrt(1.0 / 0.07))
+    for case in ("random", "zero row", "parallel"):
+        e = _f(C, D, seed=3, scale=0.5)
+        p = _f(C, D, seed=4, scale=0.125)
+        if case == "zero row":
+            e[0].zero_()
+        if case == "parallel":
+            p = (e * 0.3 + 1e-3 * _f(C, D, seed=5)).contiguous()
+        loss, de, dp = torch.empty(1, device="cuda"), torch.empty(C, D, device="cuda"), torch.empty(C, D, device="cuda")
+        hip.proxy_loss(e, p, scale, loss, de, dp)
+        e64, p64 = e.double().requires_grad_(True), p.double().requires_grad_(True)
+        a, b = scale * F.normalize(e64, p=2, dim=-1), scale * F.normalize(p64, p=2, dim=-1)
+        ref = F.cross_entropy(-((a[:, None, :] - b[None, :, :]) ** 2).sum(-1), torch.eye(C, device="cuda", dtype=torch.float64))
+        ref.backward()
+        assert abs(loss.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item())), (case, loss.item(), ref.item())
+        for got, want, name in ((de, e64.grad, "d_emb"), (dp, p64.grad, "d_proxies")):
+            if case == "zero row" and name == "d_emb":
+                got, want = got[1:], want[1:]  # the clamped row's gradient is 1e12-scaled garbage in both; compared below by finiteness only
+            if got.numel() == 0:
+                continue
+            err = (got.double() - want).abs().max().item()
+            assert err <= 2e-5 * want.abs().max().item() + 1e-9, (case, name, err, want.abs().max().item())
+        assert torch.isfinite(de).all() and torch.isfinite(dp).all()
+    assert hip.proxy_loss_supported(8, 384) and not hip.proxy_loss_supported(64, 768) and not hip.proxy_loss_supported(33, 64)
+    with pytest.raises(RuntimeError):
+        big = torch.zeros(64, 768, device="cuda")
+        hip.proxy_loss(big, big, scale, torch.empty(1, device="cuda"), torch.empty_like(big), torch.empty_like(big))
+
+
 @pytest.mark.parametrize("M", [64 * 197 + 5, 31, 5000])
 def test_gemm_tn_group(hip, M, reduction_mode):
     """dcv_gemm_tn_group: a block's four weight-gradient products (fc2, fc1, proj, qkv shapes) over the same token rows in ONE launch, both
