@@ -223,6 +223,22 @@ class _EncoderFn(torch.autograd.Function):
         return (None, None, None, None, None, None, None, dE, dpos) + tuple(grads)
 
 
+class _LinearStatsLossFn(torch.autograd.Function):
+    """sum_b stats[b] . w + c0 with a constant w [2] (DiChaViT._ortho_from_stats)."""
+
+    @staticmethod
+    def forward(ctx, stats, w, c0):
+        ctx.save_for_backward(w)
+        ctx.B = stats.shape[0]
+        out = (stats.sum(0) * w).sum()
+        return out + c0 if c0 else out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, = ctx.saved_tensors
+        return (g * w).expand(ctx.B, 2).contiguous(), None, None
+
+
 class _ChannelProxyLossFn(torch.autograd.Function):
     """proxy_loss(proxies, channel_embed, eye(C), scale) (models/loss_fn.py:7-21 as dichavit.py:399-402 calls it) with the value and both
     gradients from ONE kernel launch (dcv_proxy_loss); the backward scales the saved gradients by the incoming scalar."""
@@ -276,6 +292,7 @@ class DiChaViT(nn.Module):
         self.fused_proxy_loss = os.environ.get("DCV_FUSED_PROXY_LOSS", "1") != "0"  # the channel-embedding proxy term as one kernel (dcv_proxy_loss)
         self.wgrad_group = os.environ.get("DCV_WGRAD_GROUP", "1") != "0"  # a block's four weight gradients in one launch (needs the private scratch)
         self._group_cache = {}
+        self._stats_w = {}
         self._side = None
         self._R_cache: Dict = {}
         self._idx_cache: Dict = {}
@@ -1061,6 +1078,16 @@ class DiChaViT(nn.Module):
         T = C * n
         pos_cnt = float(np.float32(np.float32(C * n * (n - 1)) + np.float32(1e-6)))  # fp32 mask.sum() + 1e-6
         neg_cnt = float(np.float32(np.float32(T * T - C * n * n) + np.float32(1e-6)))
+        if not cfg.use_square and self.fused_proxy_loss:
+            # linear in the statistics: mean_b(gamma_s * (+-)pos_b / pos_cnt + gamma_d * neg_b / neg_cnt) (+ gamma_s) = sum_b stats_b . w + c0 with
+            # w = (+-gamma_s / pos_cnt, gamma_d / neg_cnt) / B — four launches forward and two backward instead of ~20 on a [B, 2] tensor
+            sgn = 1.0 if cfg.reverse_pos_pairs else -1.0
+            key = (stats.shape[0], C, n, str(stats.device))
+            w = self._stats_w.get(key)
+            if w is None:
+                w = self._stats_w[key] = torch.tensor([sgn * cfg.gamma_s / pos_cnt, cfg.gamma_d / neg_cnt], dtype=torch.float32,
+                                                      device=stats.device) / stats.shape[0]
+            return _LinearStatsLossFn.apply(stats, w, 0.0 if cfg.reverse_pos_pairs else float(cfg.gamma_s))
         pos = stats[:, 0] / pos_cnt
         neg = stats[:, 1] / neg_cnt
         if cfg.use_square:
