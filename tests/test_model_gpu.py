@@ -432,14 +432,15 @@ def test_loss_curve_100_steps(gpu_device):
     build (two processes printed the same digits: step0 1.06e-3, max 5.221e-3, mean 4.962e-4, last 20 steps 9.199e-5; round-to-nearest
     copies: 4.02e-4 / 6.332e-2 / 6.126e-3 / 3.619e-4; a second deterministic build with another association order in LayerNorm's
     dgamma sums: 1.06e-3 / 4.575e-3 / 4.894e-4 / 9.650e-5; a third, with eight loads in flight and 64 part lanes in the reducers:
-    1.06e-3 / 4.085e-3 / 5.184e-4 / 7.409e-5 — this curve is well conditioned, unlike the batch-2 one below; an order change in autograd's own
+    1.06e-3 / 4.085e-3 / 5.184e-4 / 7.409e-5; the final tree of round 3 (grouped weight gradients, fused regularisers): 1.06e-3 / 4.575e-3 / 4.759e-4 /
+    1.108e-4 — this curve is well conditioned, unlike the batch-2 one below; an order change in autograd's own
     accumulation of shared leaves, tried and reverted, gave 7.748e-3 / 6.975e-4 / 1.057e-4 and would need wider bounds).  With fp32 atomics
-    (round 2) eleven runs of one build spread over max 5.0e-3 .. 1.07e-2.  Bounds = 1.2 x the largest of the three deterministic builds."""
+    (round 2) eleven runs of one build spread over max 5.0e-3 .. 1.07e-2.  Bounds = 1.2 x the largest of the four deterministic builds."""
     e_sr, ref = _run_curve(gpu_device, "curve100_so2sat_s", True)
     e_rn, _ = _run_curve(gpu_device, "curve100_so2sat_s", False)
     _curve_report("loss-curve so2sat-s stochastic", e_sr, ref)
     _curve_report("loss-curve so2sat-s nearest   ", e_rn, ref)
-    assert e_sr[0] <= 1.3e-3 and e_sr.max() <= 6.3e-3 and e_sr.mean() <= 6.3e-4 and e_sr[-20:].max() <= 1.2e-4
+    assert e_sr[0] <= 1.3e-3 and e_sr.max() <= 6.3e-3 and e_sr.mean() <= 6.3e-4 and e_sr[-20:].max() <= 1.34e-4
     assert e_rn[0] <= 4.9e-4 and e_rn.max() <= 7.6e-2 and e_rn.mean() <= 7.4e-3 and e_rn[-20:].max() <= 4.4e-4
     assert e_sr.mean() < 0.5 * e_rn.mean()
 
