@@ -12,8 +12,8 @@ namespace {
 constexpr int PL_MAX_FLOATS = 16384;  // C * D per operand: two normalised copies in LDS (128 KB)
 constexpr int PL_MAX_C = 32;
 
-// one workgroup of 256 threads.  e = embeddings [C, D] (rows of the logits), p = proxies [C, D] (columns), both fp32 contiguous.
-__global__ __launch_bounds__(256) void proxy_loss_kernel(const float* __restrict__ e, const float* __restrict__ p, int C, int D, float scale,
+// one workgroup of 1024 threads (16 waves: at C = 8 every row / every four logits have a wave of their own; with 4 waves the launch took 45 us).  e = embeddings [C, D] (rows of the logits), p = proxies [C, D] (columns), both fp32 contiguous.
+__global__ __launch_bounds__(1024) void proxy_loss_kernel(const float* __restrict__ e, const float* __restrict__ p, int C, int D, float scale,
                                                          float* __restrict__ loss, float* __restrict__ de, float* __restrict__ dp) {
     extern __shared__ float sm[];
     float* en = sm;                   // [C][D] normalised embeddings
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void proxy_loss_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // 1. F.normalize(x, p=2, dim=-1): x / max(||x||, 1e-12)
-    for (int r = wave; r < 2 * C; r += 4) {
+    for (int r = wave; r < 2 * C; r += 16) {
         const float* src = (r < C) ? e + (size_t)r * D : p + (size_t)(r - C) * D;
         float* dst = (r < C) ? en + (size_t)r * D : pn + (size_t)(r - C) * D;
         float s = 0.f;
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void proxy_loss_kernel(const float* __restrict
     }
     __syncthreads();
     // 2. logits L[i][j] = -sum_d (scale * en_i[d] - scale * pn_j[d])^2
-    for (int ij = wave; ij < C * C; ij += 4) {
+    for (int ij = wave; ij < C * C; ij += 16) {
         const int i = ij / C, j = ij % C;
         float s = 0.f;
         for (int d = lane; d < D; d += 64) {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void proxy_loss_kernel(const float* __restrict
     }
     // 4. gradients.  With a_i = scale * en_i, b_j = scale * pn_j: dL_ij/da_i = -2 (a_i - b_j), dL_ij/db_j = +2 (a_i - b_j); then through
     //    the normalisation: dx = (dn - n_hat (n_hat . dn)) / max(||x||, eps)
-    for (int r = wave; r < 2 * C; r += 4) {
+    for (int r = wave; r < 2 * C; r += 16) {
         const bool is_e = r < C;
         const int i = is_e ? r : r - C;
         const float* self = (is_e ? en : pn) + (size_t)i * D;
@@ -111,7 +111,7 @@ extern "C" int dcv_proxy_loss(const float* emb, const float* proxies, int C, int
     if (lds > 64 * 1024 &&  // more than 64 KB of dynamic LDS needs the attribute (idempotent; set per call: the library keeps no state)
         hipFuncSetAttribute((const void*)proxy_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PL_MAX_FLOATS * (int)sizeof(float)) != hipSuccess)
         return DCV_ERR_LAUNCH;
-    hipLaunchKernelGGL(proxy_loss_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, emb, proxies, C, D, scale, loss, d_emb, d_proxies);
+    hipLaunchKernelGGL(proxy_loss_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, emb, proxies, C, D, scale, loss, d_emb, d_proxies);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
