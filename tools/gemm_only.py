@@ -14,7 +14,7 @@ CASES = [("nt qkv      N1152 K384  bias", "nt", A, 3 * D, hip.EPI_BIAS_BF16), ("
          ("nt dgrad    N384  K1152 plain", "nt", A3, D, hip.EPI_PLAIN_BF16), ("nt dgrad    N384  K384  plain", "nt", A, D, hip.EPI_PLAIN_BF16),
          ("nt fc2      N384  K1536 bias+resid", "nt", A4, D, hip.EPI_BIAS_RESID_F32), ("nt proj     N384  K384  bias+resid", "nt", A, D, hip.EPI_BIAS_RESID_F32),
          ("tn wgrad    P1152 Q384", "tn", A3, A, None), ("tn wgrad    P1536 Q384", "tn", A4, A, None), ("tn wgrad    P384  Q1536", "tn", A, A4, None),
-         ("tn wgrad    P384  Q384", "tn", A, A, None)]
+         ("tn wgrad    P384  Q384", "tn", A, A, None), ("tn group    fc2+fc1+proj+qkv", "tng", None, None, None)]
 if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     for name, kind, a, n_or_x, epi in CASES:
@@ -28,6 +28,12 @@ if __name__ == "__main__":
             torch.cuda.synchronize()
             for _ in range(reps):
                 hip.gemm_nt(a, W, epi, out, bias=bias, out2=out2, aux=aux)
+        elif kind == "tng":  # a block's four weight gradients in one launch (dcv_gemm_tn_group)
+            prods = [(A, A4), (A4, A), (A, A), (A3, A)]
+            outs = [(torch.zeros(Y.shape[1], X.shape[1], device="cuda"), torch.zeros(Y.shape[1], device="cuda")) for Y, X in prods]
+            torch.cuda.synchronize()
+            for _ in range(reps):
+                hip.gemm_tn_acc_group([(Y, X, dW, db) for (Y, X), (dW, db) in zip(prods, outs)])
         else:
             Y, X = a, n_or_x
             dW = torch.zeros(Y.shape[1], X.shape[1], device="cuda"); db = torch.zeros(Y.shape[1], device="cuda")
