@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15  # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12   # HBM3E spec (6.29 TB/s measured with a float4 copy), MI355X_MICROARCH.md
+RIDGE = PEAK_BF16 / PEAK_HBM  # 312.5 FLOP per HBM byte: below it a kernel is HBM-bound on paper
 TRAIN_GFLOP_PER_IMG = 336.94  # BASELINE.md §3 (matmul-only, train = 3 x fwd)
 DEAD_GFLOP_PER_IMG = 23.82    # rows of the last block that never reach the output
 
@@ -90,6 +91,9 @@ def cpu_baseline(cfg, channels, img, classes, sample_bs=8, steps=3):
             times.append(time.time() - t0)
     dt = float(np.median(times))
     return {"value": round(sample_bs / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            # the reference cannot travel to the GPU box; its own rate was measured in the build container
+            "reference_itself": {"value": 0.63, "unit": "images/sec", "cores": 8, "where": "the real reference (fp32, CPU, same model and batch shape) "
+                                 "in the build container, BASELINE.md section 2 — not timed on this box"},
             "sample": f"median of {steps} timed fp32 train steps (after 1 warm-up) of the same model at batch {sample_bs} on the host CPU "
                       f"({dt:.1f} s per step)"}
 
@@ -116,7 +120,10 @@ def table_from(prof, n_steps, step_ms):
         row = {"symbol": sym, "shape": shape, "launches_per_step": round(len(ts) / n_steps, 2), "avg_us": round(avg * 1e3, 1),
                "ms_per_step": round(sum(ts) / n_steps, 3), "share_of_step": round(sum(ts) / n_steps / step_ms, 4)}
         if r["flops"] > 0:
-            row.update(bound="mfma", gflop=round(r["flops"] / 1e9, 2), gflop_executed=round(r["flops_exec"] / 1e9, 2),
+            # which roofline binds THIS launch: its arithmetic intensity (executed FLOPs per algorithmic HBM byte) against the ridge
+            # PEAK_BF16 / PEAK_HBM = 312.5 FLOP/B.  Every D = 384 GEMM of the encoder sits below it (170-290 FLOP/B): HBM-bound on paper.
+            ai = r["flops_exec"] / r["bytes"] if r["bytes"] > 0 else float("inf")
+            row.update(bound="mfma" if ai >= RIDGE else "hbm", flop_per_byte=round(ai, 1) if ai != float("inf") else None, gflop=round(r["flops"] / 1e9, 2), gflop_executed=round(r["flops_exec"] / 1e9, 2),
                        achieved_tflops=round(r["flops"] / (avg * 1e-3) / 1e12, 1), frac=round(r["flops"] / (avg * 1e-3) / PEAK_BF16, 4),
                        frac_executed=round(r["flops_exec"] / (avg * 1e-3) / PEAK_BF16, 4))
         if r["bytes"] > 0:
@@ -294,15 +301,13 @@ def main():
         for r in table:
             print(f"  {r['symbol']:28s} {r['shape']:26s} x{r['launches_per_step']:5.1f} {r['avg_us']:8.1f} us  {r['ms_per_step']:7.3f} ms/step "
                   f"{100 * r['share_of_step']:5.1f} %  " + (f"{r.get('achieved_tflops', 0):7.1f} TF/s ({100 * r.get('frac', 0):4.1f} % alg / "
-                  f"{100 * r.get('frac_executed', 0):4.1f} % exec)" if r.get("bound") == "mfma" else f"{r.get('achieved_gbps', 0):7.0f} GB/s"), file=sys.stderr)
+                  f"{100 * r.get('frac_executed', 0):4.1f} % exec, {r.get('flop_per_byte')} FLOP/B -> {r.get('bound')})" if r.get("gflop") else f"{r.get('achieved_gbps', 0):7.0f} GB/s"), file=sys.stderr)
 
     # ---- timed region: EXACTLY K steps; events only around the dominant symbol's launches (eager) ----
     if use_graph:
         graphed(x, y)  # capture (plus its own eager warm-up steps)
         step = lambda: graphed(x, y)  # noqa: E731
         step()
-    else:
-        hip.set_profiler(True, only=[dominant])
     if args.h2d:
         xh, yh = x.cpu().pin_memory(), y.cpu().pin_memory()
         bufs = [(torch.empty_like(x), torch.empty_like(y)) for _ in range(2)]
@@ -333,25 +338,58 @@ def main():
             loss = inner(x, y) if inner is not None else eager_step()
             consumed[slot].record()
             return loss
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    picks0 = sum(model.feature_extractor.patch_embed.counter.values()) if args.hcs else 0  # channel draws so far (HCS histogram)
-    sync()
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        loss = step()
-        marks[i + 1].record()
-    sync()
-    dt = time.perf_counter() - t0
-    live = None if use_graph else hip.set_profiler(False)
-    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
-    med_ms = float(np.median(step_ms))
-    if os.environ.get("DCV_BENCH_STEP_TIMES") and rank == 0:
-        print("step ms:", " ".join(f"{v:.1f}" for v in step_ms), file=sys.stderr)
-    if use_dp:
-        t = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, med_ms = t[0].item(), t[1].item()
+    picks0 = 0
+
+    def timed_region():
+        """EXACTLY K steps between barrier + synchronize pairs; returns (seconds, median step ms, per-launch records of the dominant symbol)."""
+        nonlocal picks0
+        picks0 = sum(model.feature_extractor.patch_embed.counter.values()) if args.hcs else 0  # channel draws so far (HCS histogram)
+        if not use_graph:
+            hip.set_profiler(True, only=[dominant])
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        sync()
+        t0 = time.perf_counter()
+        marks[0].record()
+        loss_ = None
+        for i in range(args.steps):
+            loss_ = step()
+            marks[i + 1].record()
+        sync()
+        dt_ = time.perf_counter() - t0
+        live_ = None if use_graph else hip.set_profiler(False)
+        step_ms_ = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        med_ = float(np.median(step_ms_))
+        if os.environ.get("DCV_BENCH_STEP_TIMES") and rank == 0:
+            print("step ms:", " ".join(f"{v:.1f}" for v in step_ms_), file=sys.stderr)
+        if use_dp:
+            t = torch.tensor([dt_, med_], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_, med_ = t[0].item(), t[1].item()
+        return dt_, med_, live_, loss_
+
+    # N > 1 (VERDICT r3 item 5): BOTH exchange modes are timed in this one invocation, same process group, K steps each — the overlapped
+    # per-layer buckets first (north_star's mode and the library default), then one all-reduce after the backward; `value` is the better of
+    # the two and `dp.modes` carries both.  --overlap / --no-overlap restrict the run to one mode.
+    dp_modes = {}
+    if dp is not None and not (args.overlap or args.no_overlap):
+        order = [True, False]
+    else:
+        order = [bool(args.overlap) if dp is not None and (args.overlap or args.no_overlap) else (dp.overlap if dp is not None else None)]
+    best = None
+    for mi, mode in enumerate(order):
+        if dp is not None:
+            dp.overlap = bool(mode)
+            if mi > 0:
+                for _ in range(2):  # untimed: the first steps in a mode allocate its buffers
+                    step()
+        r = timed_region()
+        if dp is not None:
+            dp_modes["overlap" if mode else "single_allreduce_after_backward"] = {
+                "images_per_sec": round(args.batch * world * args.steps / r[0], 2), "ms_per_step": round(r[0] / args.steps * 1e3, 3),
+                "median_ms_per_step": round(r[1], 3)}
+        if best is None or r[0] < best[1][0]:
+            best = (mode, r)
+    chosen_mode, (dt, med_ms, live, loss) = best
     final_loss = loss.item()
 
     if rank == 0:
@@ -400,13 +438,27 @@ def main():
         if pmc_path:
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            if dominant in pmc:
+            if dominant in pmc and dominant != "_meta":
                 v = pmc[dominant]
                 roof["traffic"] = round(v["read_bytes_per_launch"] + v["written_bytes_per_launch"])
                 roof["traffic_unit"] = "bytes/launch (HBM, PMC: 2 x FETCH_SIZE + WRITE_SIZE)"
                 roof["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
+        # ---- the roofline that binds the STEP: executed FLOPs at the dense bf16 peak against HBM bytes (PMC, whole step)
+        # at the HBM peak.  The PMC passes cover `steps` whole steps of this command (tools/pmc_traffic.sh: 2 timed + 1 warm-up).
+        step_roof = None
+        if pmc and headline:
+            pmc_steps = (pmc.get("_meta") or {}).get("steps", 3)
+            tot = sum((v["read_bytes_per_launch"] + v["written_bytes_per_launch"]) * v["launches"] for k, v in pmc.items() if k != "_meta") / pmc_steps
+            step_ms_now = dt / args.steps * 1e3
+            exec_flop = (TRAIN_GFLOP_PER_IMG - (DEAD_GFLOP_PER_IMG if model.cls_only_tail else 0.0)) * 1e9 * args.batch
+            mfma_ms, hbm_ms = exec_flop / PEAK_BF16 * 1e3, tot / PEAK_HBM * 1e3
+            step_roof = {"step_hbm_gbytes": round(tot / 1e9, 2), "step_hbm_floor_ms": round(hbm_ms, 2), "step_hbm_frac": round(hbm_ms / step_ms_now, 4),
+                         "step_executed_tflop": round(exec_flop / 1e12, 2), "step_mfma_floor_ms": round(mfma_ms, 2), "step_mfma_frac": round(mfma_ms / step_ms_now, 4),
+                         "step_bound": "hbm" if hbm_ms >= mfma_ms else "mfma", "step_frac_of_binding_roofline": round(max(hbm_ms, mfma_ms) / step_ms_now, 4),
+                         "step_hbm_achieved_gbps": round(tot / (step_ms_now * 1e-3) / 1e9, 0),
+                         "source": "HBM bytes: 2 x FETCH_SIZE + WRITE_SIZE summed over every kernel of a step, profiles/" + os.path.basename(pmc_path)}
         for r in table:  # per-symbol PMC traffic next to the algorithmic bytes (mean over the symbol's shapes in the PMC run)
-            if r["symbol"] in pmc:
+            if r["symbol"] in pmc and r["symbol"] != "_meta":
                 v = pmc[r["symbol"]]
                 r["pmc_mbytes_per_launch"] = round((v["read_bytes_per_launch"] + v["written_bytes_per_launch"]) / 1e6, 1)
         # matrix-pipe utilisation per (symbol, shape) from the committed SQ-counter passes (tools/pmc_gemm.sh at the headline shapes):
@@ -463,6 +515,7 @@ def main():
                        **({"chammi": "12-channel model, sub-batches Allen 3ch / HPA 4ch / CP 5ch (N = 589 / 785 / 981 tokens), proxy main loss, "
                                      "3 forward/backward passes + 1 optimiser step per step; img/s counts the images of all three"} if args.chammi else {})},
             "roofline": roof,
+            "step_roofline": step_roof,
             "kernel_table_mode": "per-launch durations from the profiled warm-up steps, run on one stream (exclusive); "
                                  "ms_per_step and share_of_step refer to that one-stream step",
             "kernel_table": table[:24],
@@ -472,7 +525,10 @@ def main():
             line["dp"] = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "buckets_launched": dp.buckets_launched,
                           "buckets_per_step": round(dp.buckets_launched / max(steps_run, 1), 2),
                           "mbytes_reduced_per_step": round(dp.bytes_reduced / max(steps_run, 1) / 1e6, 2), "grad_dtype": args.grad_dtype,
-                          "overlap": bool(args.overlap), "rccl_channels_requested": os.environ.get("NCCL_MAX_NCHANNELS"),
+                          "overlap": bool(chosen_mode), "modes": dp_modes,
+                          "mode_choice": ("both exchange modes timed in this invocation (K steps each, same process group); value / ms_per_step are "
+                                          "the faster one's" if len(dp_modes) > 1 else "one mode timed (--overlap / --no-overlap)"),
+                          "rccl_channels_requested": os.environ.get("NCCL_MAX_NCHANNELS"),
                           "rccl_channels_in_use": None,  # filled in below, once the communicator is gone and its log complete
                           "reserved_cus": dp.reserved_cus}
         if world == 1 and not args.no_cpu_baseline:

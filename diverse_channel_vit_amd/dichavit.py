@@ -290,6 +290,10 @@ class DiChaViT(nn.Module):
         self.wgrad_stream = True  # the backward runs the weight-gradient GEMMs on a second HIP stream (_run_backward_body); False: one stream
         self.wgrad_private_scratch = os.environ.get("DCV_WGRAD_PRIVATE", "1") != "0"  # per-layer scratch instead of reader waits (_run_backward_body)
         self.fused_proxy_loss = os.environ.get("DCV_FUSED_PROXY_LOSS", "1") != "0"  # the channel-embedding proxy term as one kernel (dcv_proxy_loss)
+        # attention backward in one pass (dcv_attn_bwd_fused: 5 products, operands read once, dQ by an ordered, bit-reproducible hand-off).  Parity-green
+        # but measured SLOWER than the dQ + dK/dV pair at the headline shape in round 4 (1100-1500 us against 865 us per layer: the hand-off's
+        # ~5 us edge latency against a 3.6-iteration budget per edge, profiles/r04_x1_*), so it is opt-in: DCV_ATTN_BWD_FUSED=1 / model.attn_bwd_fused = True
+        self.attn_bwd_fused = os.environ.get("DCV_ATTN_BWD_FUSED", "0") == "1"
         self.wgrad_group = os.environ.get("DCV_WGRAD_GROUP", "1") != "0"  # a block's four weight gradients in one launch (needs the private scratch)
         self._group_cache = {}
         self._stats_w = {}
@@ -895,7 +899,10 @@ class DiChaViT(nn.Module):
                     dqkv = torch.empty_like(dqkv)
                 else:
                     before_write("dqkv")
-                hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
+                if self.attn_bwd_fused:
+                    hip.attn_bwd_fused(L["qkv"], L["o"], dO, L["lse"], dqkv, B, N, H, D // H, scale)
+                else:
+                    hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
             hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du, **nt_kw)
             wgrad_or_collect(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv", grouped)
             if grouped:

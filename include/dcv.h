@@ -153,6 +153,17 @@ int dcv_attn_bwd_dq_rows(const void* qkv, const void* o, const void* dO, const f
 int dcv_attn_bwd_dkdv_rows(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
                            int H, int head_dim, float scale, void* stream);
 
+/* The same gradients in ONE pass (five N x N x 64 products instead of seven; Q, K, V, dO read once): one workgroup per 256 keys keeps
+ * dK / dV in registers, dQ is summed across the key blocks of a (batch, head) by an ordered, bit-reproducible hand-off of f32 partial tiles
+ * (no atomics) through ws.  ws: dcv_attn_bwd_fused_ws_bytes(B, N, H) bytes, 256-byte aligned, caller-owned scratch (statistics, flags and
+ * partial tiles; contents are rewritten by every call).  All query rows (the Nq < N forms stay on the two-kernel path).  Returns
+ * DCV_ERR_UNSUPPORTED when a chain of key blocks cannot be resident at once (N > 65 536).  dcv_attn_bwd_fused_err_ptr: device address of
+ * a word the kernel sets to 1 when a wave gave up waiting for its predecessor (results then undefined; never seen on in-order dispatch). */
+size_t dcv_attn_bwd_fused_ws_bytes(int B, int N, int H);
+int dcv_attn_bwd_fused(const void* qkv, const void* o, const void* dO, const float* lse, void* ws, void* dqkv, int B, int N, int H,
+                       int head_dim, float scale, void* stream);
+const void* dcv_attn_bwd_fused_err_ptr(const void* ws, int B, int N, int H);
+
 /* x [B,Ct,H,W] f32 (x_is_u8 == 0: normalised images, the reference's batch format) or u8 (raw pixels), ch_idx int32[C]
  * (device) -> bf16 [B*C*(H/P)*(W/P), P*P] patch rows (dichavit.py:134/210,377).  scale/shift f32[C] (nullable, indexed by
  * gathered position): x*scale[c] + shift[c], i.e. the (x/255 - mean_c)/std_c of the CPU pipeline

@@ -26,18 +26,48 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 handles = [C.CDLL(l) for l in libs]
 
 
+wsf = {}
+errw = {}
+
+
+def fused(h):
+    if not hasattr(h, "dcv_attn_bwd_fused"):
+        return None
+    h.dcv_attn_bwd_fused_ws_bytes.restype = C.c_size_t
+    nb = h.dcv_attn_bwd_fused_ws_bytes(B, N, H)
+    buf = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
+    off = (-buf.data_ptr()) % 256
+    wsf[id(h)] = buf
+    wp = C.c_void_p(buf.data_ptr() + off)
+    h.dcv_attn_bwd_fused_err_ptr.restype = C.c_void_p
+    eoff = h.dcv_attn_bwd_fused_err_ptr(wp, B, N, H) - buf.data_ptr()
+    errw[id(h)] = lambda: buf[eoff:eoff + 128].view(torch.int32).tolist()
+    return lambda: h.dcv_attn_bwd_fused(p(qkv), p(o), p(dO), p(lse), wp, p(dqkv), B, N, H, 64, C.c_float(0.125), st)
+
+
 def calls(h):
+    f = fused(h)
+    d = _calls(h)
+    if f is not None:
+        d["fused"] = f
+    return d
+
+
+def _calls(h):
     return {"fwd": lambda: h.dcv_attn_fwd_rows(p(qkv), p(o), p(lse), B, N, N, H, 64, C.c_float(0.125), st),
             "dq": lambda: h.dcv_attn_bwd_dq_rows(p(qkv), p(o), p(dO), p(lse), p(ws), p(dqkv), B, N, N, H, 64, C.c_float(0.125), st),
             "dkdv": lambda: h.dcv_attn_bwd_dkdv_rows(p(qkv), p(dO), p(lse), p(ws), p(dqkv), B, N, N, H, 64, C.c_float(0.125), st)}
 
 
 fns = [calls(h) for h in handles]
-res = {(i, k): [] for i in range(len(libs)) for k in ("fwd", "dq", "dkdv")}
+KEYS = ("fwd", "dq", "dkdv", "fused")
+res = {(i, k): [] for i in range(len(libs)) for k in KEYS}
 outs = {}
 for rnd in range(int(os.environ.get("AB_ROUNDS", 12))):
     for i, f in enumerate(fns):
-        for k in ("fwd", "dq", "dkdv"):
+        for k in KEYS:
+            if k not in f:
+                continue
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             rc = f[k]()
@@ -49,7 +79,9 @@ for rnd in range(int(os.environ.get("AB_ROUNDS", 12))):
         if rnd == 0:
             outs[i] = (o.float().clone(), dqkv.float().clone())
 for i, l in enumerate(libs):
-    t = {k: res[(i, k)] for k in ("fwd", "dq", "dkdv")}
+    if id(handles[i]) in errw:
+        print("  err / slow-path entries / spins / entries by iteration:", errw[id(handles[i])]())
+    t = {k: res[(i, k)] for k in KEYS if res[(i, k)]}
     same = "" if i == 0 else f"  max|dO-ref| {float((outs[i][0] - outs[0][0]).abs().max()):.3g} max|dqkv-ref| {float((outs[i][1] - outs[0][1]).abs().max()):.3g}"
     print(f"{os.path.basename(l):40s} " + "  ".join(f"{k} {np.median(v):7.1f} (min {min(v):7.1f})" for k, v in t.items()) +
-          f"  sum {sum(np.median(v) for v in t.values()):7.1f} us" + same)
+          f"  sum(fwd,dq,dkdv) {sum(np.median(t[k]) for k in ('fwd', 'dq', 'dkdv')):7.1f} us" + same)

@@ -1,4 +1,4 @@
-"""Runs only the attention entries at the headline shape (for rocprofv3 --pmc passes)."""
+"""Runs only the attention entries at the headline shape (for rocprofv3 --pmc passes).  argv: repeats [fused|pair|all]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diverse_channel_vit_amd import hip
@@ -7,7 +7,11 @@ B, N, H, D = 64, 1569, 6, 384
 torch.manual_seed(0)
 qkv = torch.randn(B, N, 3 * D, device="cuda").to(torch.bfloat16); o = torch.empty(B, N, D, dtype=torch.bfloat16, device="cuda"); lse = torch.empty(B, H, N, device="cuda")
 dO = torch.randn(B, N, D, device="cuda").to(torch.bfloat16); dqkv = torch.empty_like(qkv); delta = torch.empty(2, B, H, N, device="cuda")
+what = sys.argv[2] if len(sys.argv) > 2 else "all"
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     hip.attn_fwd(qkv, o, lse, B, N, H, 64, 0.125)
-    hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, 0.125)
+    if what in ("pair", "all"):
+        hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, 0.125)
+    if what in ("fused", "all"):
+        hip.attn_bwd_fused(qkv, o, dO, lse, dqkv, B, N, H, 64, 0.125)
 torch.cuda.synchronize()

@@ -11,6 +11,9 @@ M, D = 64 * 1569, 384
 bf = torch.bfloat16
 torch.manual_seed(0)
 A = torch.randn(M, D, device="cuda").to(bf); A4 = torch.randn(M, 4 * D, device="cuda").to(bf)
+ZERO = bool(os.environ.get("GB_ZERO"))
+if ZERO:
+    A.zero_(); A4.zero_()
 cases = [("qkv  N1152 K384  bias->bf16", A, 3 * D, hip.EPI_BIAS_BF16), ("fc1  N1536 K384  bias+GELU (2 outputs)", A, 4 * D, hip.EPI_BIAS_GELU_BF16),
          ("fc2  N384  K1536 bias+resid f32", A4, D, hip.EPI_BIAS_RESID_F32), ("dgrad N384 K1536 plain bf16", A4, D, hip.EPI_PLAIN_BF16),
          ("gelu-bwd N1536 K384", A, 4 * D, hip.EPI_GELU_BWD_BF16), ("proj N384 K384 bias+resid", A, D, hip.EPI_BIAS_RESID_F32)]
@@ -19,6 +22,8 @@ print("tile:", "256x128" if tile == hip.TILE_NARROW else "256x384", "(cycles are
 for name, a, N, epi in cases:
     K = a.shape[1]
     W = (torch.randn(N, K, device="cuda") * 0.05).to(bf)
+    if ZERO:
+        W.zero_()
     bias = torch.zeros(N, device="cuda")
     out = torch.empty(M, N, dtype=torch.float32 if epi == hip.EPI_BIAS_RESID_F32 else bf, device="cuda")
     out2 = torch.empty(M, N, dtype=bf, device="cuda") if epi == hip.EPI_BIAS_GELU_BF16 else None

@@ -32,6 +32,7 @@ for k, d in agg.items():
     rd = 2 * 1024 * d["FETCH_SIZE"][0] / max(d["FETCH_SIZE"][1], 1)
     wr = 1024 * d["WRITE_SIZE"][0] / max(d["WRITE_SIZE"][1], 1)
     res[k] = dict(launches=n, read_bytes_per_launch=rd, written_bytes_per_launch=wr)
+res["_meta"] = dict(steps=3, command="bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline", counters="FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KiB -> bytes")
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 print("kernels:", len(res))
 PY

@@ -1,0 +1,28 @@
+#!/bin/bash
+# round-4 GPU call A: fused attention backward parity + timing; NT GEMM ablations on random vs all-zero operands
+set -o pipefail
+out=gpurun_out/r4a; mkdir -p $out
+timeout -k 10 420 python -m pytest tests/test_kernels_gpu.py -x -q -k "attention" > $out/pytest_attn.log 2>&1 || { tail -30 $out/pytest_attn.log; exit 1; }
+tail -3 $out/pytest_attn.log
+timeout -k 10 200 python tools/attn_bench.py > $out/attn_bench.txt 2>&1 || { tail $out/attn_bench.txt; exit 1; }
+cat $out/attn_bench.txt
+AB_ZERO=1 timeout -k 10 200 python tools/attn_bench.py > $out/attn_bench_zero.txt 2>&1; cat $out/attn_bench_zero.txt
+for z in "" 1; do
+  for v in base gabl1 gabl2 gabl3; do
+    if [ "$v" = base ]; then lib=diverse_channel_vit_amd/libdcv_hip.so; else lib=diverse_channel_vit_amd/libdcv_hip_$v.so; fi
+    echo "== $v zero=${z:-0}" | tee -a $out/gemm_ablation_zero_ab.txt
+    GB_ZERO=$z DCV_LIB=$PWD/$lib GB_ROUNDS=8 timeout -k 10 240 python tools/gemm_bench.py 2>&1 | grep -v amdgpu.ids | tee -a $out/gemm_ablation_zero_ab.txt || exit 1
+  done
+  for t in wide narrow; do
+    echo "== stamp tile=$t zero=${z:-0}" | tee -a $out/gemm_stamp_zero_ab.txt
+    GB_ZERO=$z STAMP_TILE=$t DCV_LIB=$PWD/diverse_channel_vit_amd/libdcv_hip_stamp.so timeout -k 10 120 python tools/gemm_stamp.py 2>&1 | grep -v amdgpu.ids | tee -a $out/gemm_stamp_zero_ab.txt || exit 1
+  done
+done
+for f in 1 0; do
+  DCV_ATTN_BWD_FUSED=$f timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $out/bench_fused$f.json 2> $out/bench_fused$f.err || { tail $out/bench_fused$f.err; exit 1; }
+  python - <<PY
+import json
+d=json.loads(open("$out/bench_fused$f.json").read().strip().splitlines()[-1])
+print("fused=$f", d["value"], d["ms_per_step"])
+PY
+done
