@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="(accepted for round-2 command lines: the default now)")
     ap.add_argument("--wgrad-stream", type=int, default=None, choices=[0, 1], help="weight-gradient GEMMs on a second HIP stream (default: the model's default)")
     ap.add_argument("--hcs", action="store_true", help="secondary run (SURVEY §8d): enable_sample=True, hcs_sampling=lowest_cosine_prob, temp 1000 "
-                                                     "(variable sequence length, one host sync per step like the reference)")
+                                                     "(variable sequence length; the sampled subset stays on the device: no host sync per step)")
     ap.add_argument("--chammi", action="store_true", help="secondary run (SURVEY §8d, BASELINE config 3): the CHAMMI step of trainer.py:846-935 — a 12-channel "
                                                         "model, the batch split into Allen / HPA / CP sub-batches of 3 / 4 / 5 channels, proxy main loss on the "
                                                         "features, three forward/backward passes accumulate into one optimiser step")
@@ -338,11 +338,12 @@ def main():
             loss = inner(x, y) if inner is not None else eager_step()
             consumed[slot].record()
             return loss
-    picks0 = 0
+    picks0 = syncs0 = 0
 
     def timed_region():
         """EXACTLY K steps between barrier + synchronize pairs; returns (seconds, median step ms, per-launch records of the dominant symbol)."""
-        nonlocal picks0
+        nonlocal picks0, syncs0
+        syncs0 = model.host_syncs
         picks0 = sum(model.feature_extractor.patch_embed.counter.values()) if args.hcs else 0  # channel draws so far (HCS histogram)
         if not use_graph:
             hip.set_profiler(True, only=[dominant])
@@ -500,7 +501,9 @@ def main():
                                      if model.cls_only_tail else "none skipped"),
                        "final_loss": round(final_loss, 5),
                        "input": ("pinned host memory -> HBM every step (copy stream, double-buffered)" if args.h2d else "resident in HBM"),
-                       "host_syncs_per_step": 0,
+                       # synchronisations the model's own code causes per step (the reference's HCS branch moves the sampled subset to the host
+                       # every step, dichavit.py:178/184/200; here it stays on the device unless DCV_HCS_ON_DEVICE=0)
+                       "host_syncs_per_step": round((model.host_syncs - syncs0) / max(args.steps * len(order), 1), 3),
                        "launch": "hip-graph replay of the captured step" if use_graph else "eager",
                        "wgrad_stream": bool(model.wgrad_stream),
                        "wgrad_group": bool(model.wgrad_group and model.wgrad_private_scratch),  # a block's four weight gradients in one launch

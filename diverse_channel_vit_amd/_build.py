@@ -30,14 +30,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(name: str, defines, verbose: bool = True, flags=()) -> str:
-    """A/B build of the same ABI with extra -D flags -> libdcv_hip_<name>.so (select it with DCV_LIB=...)."""
+#: diagnostic translation units that REPLACE a product source in a variant build: the stamp / ablation / wrap / stagger harness of the GEMM kernels
+#: lives in tools/probes/gemm_instrumented.hip (the shipped csrc/gemm.hip carries none of it: VERDICT r3 item 8)
+INSTRUMENTED = {"gemm.hip": os.path.join(HERE, "..", "tools", "probes", "gemm_instrumented.hip")}
+
+
+def build_variant(name: str, defines, verbose: bool = True, flags=(), instrumented=()) -> str:
+    """A/B build of the same ABI with extra -D flags -> libdcv_hip_<name>.so (select it with DCV_LIB=...).
+    instrumented: product sources to replace by their diagnostic twin (INSTRUMENTED), e.g. ("gemm.hip",) for -DDCV_STAMP=1 / -DDCV_GABL=n."""
     objdir = os.path.join(HERE, "build", "variant_" + name)
     os.makedirs(objdir, exist_ok=True)
     objs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + list(flags) + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
+        base = os.path.basename(src)
+        if base in instrumented:
+            src = os.path.abspath(INSTRUMENTED[base])
+        cmd = [HIPCC] + FLAGS + EXTRA.get(base, []) + list(flags) + ["-I" + CSRC] + ["-D" + d for d in defines] + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

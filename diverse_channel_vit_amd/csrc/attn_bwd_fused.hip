@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_fused_stats_kernel(const bf16_t* __r
                                                                int nflags, unsigned* err, int B, int N, int H, int Tp) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (idx < (size_t)nflags) flags[idx] = 0u;
-    if (idx < 32) err[idx] = 0u;
+    if (idx == 0) *err = 0u;
     const size_t total = (size_t)B * Tp * H;
     if (idx >= total) return;
     const int hh = idx % H;
@@ -382,14 +382,6 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(FusedArgs a) {
                     if (lane == 0) *a.err = 1u;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-#ifdef FB_SPIN_STATS
-                if (lane == 0) {
-                    atomicAdd(a.err + 1, 1u);
-                    atomicAdd(a.err + 2, spins + 1);
-                    atomicAdd(a.err + 4 + (it < 28 ? it : 27), 1u);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-#endif
             }
             const float* src = (has_pred ? pred_part : my_part) + (size_t)tau_prev * 4096 + lane_part;
             f32x4 l0 = fb_ld16_sc1(src), l1 = fb_ld16_sc1(src + 256);  // L

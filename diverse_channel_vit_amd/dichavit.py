@@ -91,6 +91,78 @@ class _PosResample(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # parameter containers (names = the reference's state_dict keys)
 # ------------------------------------------------------------------------------------------------
+def hcs_pick(cos: torch.Tensor, k: int, mode: str, temp: float) -> torch.Tensor:
+    """The subset draw of HCS (dichavit.py:176-206) on whatever device `cos` lives: positions of the k channels picked from the anchor's cosine
+    row, BEFORE the anchor is forced in (:201-202).  Device-agnostic on purpose: tests/test_init_cpu.py replays the reference's recorded draws
+    through it on the CPU (torch's CPU and GPU multinomial streams differ, so only the CPU can reproduce the reference's own picks)."""
+    if mode == "lowest_cosine":
+        return torch.topk(cos, k=k, largest=False).indices  # :178
+    if mode == "highest_cosine":
+        return torch.topk(cos, k=k, largest=True).indices  # :184
+    if mode in ("lowest_cosine_prob", "lowest_cosine_prob_proj"):
+        prob = F.softmax((1 - cos) / temp, dim=-1)  # :194-196
+        return torch.multinomial(prob, k, replacement=False)  # :199
+    raise ValueError(f"Invalid hcs_sampling: '{mode}'")  # :206
+
+
+def hcs_force_anchor(ind: torch.Tensor, anchor: int) -> torch.Tensor:
+    """`if anchor not in ind: ind[-1] = anchor` (dichavit.py:201-202) without reading `ind` on the host."""
+    out = ind.clone()
+    out[-1] = torch.where((ind == anchor).any(), ind[-1], torch.full_like(ind[-1], anchor))
+    return out
+
+
+class _DevList:
+    """A channel list that lives on the device: `.t` int64 tensor of known length `.n` (len() works without touching the values)."""
+    __slots__ = ("t", "n")
+
+    def __init__(self, t, n):
+        self.t, self.n = t, int(n)
+
+    def __len__(self):
+        return self.n
+
+
+class _PickCounter(defaultdict):
+    """`patch_embed.counter` of the reference (a defaultdict(lambda: 0) of picks per global channel id, dichavit.py:66, 214-216; read once
+    per epoch by trainer.py:799).  The HCS sampler draws its subset on the device and, to stay off the host's critical path, counts the
+    picks there too (`add_device`); any READ of the dictionary first copies those counts over — one synchronisation, where the caller asked
+    for the numbers, instead of one per training step."""
+
+    def __init__(self, *_):
+        super().__init__(int)
+        self._dev = None
+
+    def __reduce__(self):  # copy / deepcopy / pickle: the counts as a plain mapping (the reference's lambda factory cannot be pickled at all)
+        self._flush()
+        return (_PickCounter, (), None, None, iter(list(defaultdict.items(self))))
+
+    def add_device(self, ids: torch.Tensor, size: int) -> None:
+        if self._dev is None or self._dev.device != ids.device or self._dev.numel() < size:
+            self._flush()
+            self._dev = torch.zeros(size, dtype=torch.int64, device=ids.device)
+        self._dev.index_add_(0, ids, torch.ones_like(ids))
+
+    def _flush(self) -> None:
+        d, self._dev = self._dev, None
+        if d is not None:
+            for k, v in enumerate(d.cpu().tolist()):
+                if v:
+                    defaultdict.__setitem__(self, k, defaultdict.__getitem__(self, k) + v)
+
+    def _make(name):
+        def f(self, *a, **kw):
+            self._flush()
+            return getattr(defaultdict, name)(self, *a, **kw)
+        f.__name__ = name
+        return f
+
+    for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "items", "keys", "values", "get", "clear", "copy", "pop",
+               "__eq__", "__setitem__", "__delitem__"):
+        locals()[_n] = _make(_n)
+    del _n, _make
+
+
 class _Holder(nn.Module):
     def forward(self, *a, **k):  # pragma: no cover
         raise RuntimeError("parameter container of the HIP path; call DiChaViT.forward")
@@ -136,7 +208,7 @@ class PatchEmbedPerChannel(_Holder):
                 nn.init.orthogonal_(self.channel_emb_proxies)
         hcs = _cfg_get(cfg, "hcs_sampling", "none")
         if hcs != "none" and hcs is not None:
-            self.counter = defaultdict(lambda: 0)
+            self.counter = _PickCounter()  # a defaultdict(lambda: 0) (dichavit.py:66) whose reads first fold in the picks counted on the device
             if str(hcs).endswith("resnet34"):
                 raise ValueError("hcs_sampling=*_resnet34 needs a pretrained timm download; not available (SURVEY §8a a8)")
         self.proj = nn.Conv3d(1, embed_dim, kernel_size=(1, patch_size, patch_size), stride=(1, patch_size, patch_size))
@@ -294,12 +366,15 @@ class DiChaViT(nn.Module):
         # but measured SLOWER than the dQ + dK/dV pair at the headline shape in round 4 (1100-1500 us against 865 us per layer: the hand-off's
         # ~5 us edge latency against a 3.6-iteration budget per edge, profiles/r04_x1_*), so it is opt-in: DCV_ATTN_BWD_FUSED=1 / model.attn_bwd_fused = True
         self.attn_bwd_fused = os.environ.get("DCV_ATTN_BWD_FUSED", "0") == "1"
+        self.wgrad_scratch_release = os.environ.get("DCV_WGRAD_RELEASE", "1") != "0"  # hand a layer's private scratch back once its last reader is queued
         self.wgrad_group = os.environ.get("DCV_WGRAD_GROUP", "1") != "0"  # a block's four weight gradients in one launch (needs the private scratch)
         self._group_cache = {}
         self._stats_w = {}
         self._side = None
         self._R_cache: Dict = {}
         self._idx_cache: Dict = {}
+        self.hcs_on_device = os.environ.get("DCV_HCS_ON_DEVICE", "1") != "0"  # the sampled subset stays on the device (no per-step host sync)
+        self.host_syncs = 0  # host synchronisations the model's own code has caused (the legacy HCS path: one per training step)
         self.hcs_sampler = None  # optional callable(model, chunk_name, cur_channels) -> (picked ids, positions): pins the subset
         self.drop_path_sampler = None  # optional callable(block, "attn" | "mlp", B, device) -> 0/1 keep mask [B]: pins DropPath's draws
         self._in_scale = self._in_shift = None  # optional per-global-channel input affine (set_input_normalisation)
@@ -428,6 +503,10 @@ class DiChaViT(nn.Module):
         """Channel index lists live on the device once (no host->device copy per step; graph-capture safe).  Only the
         channel lists are cached (a few dozen distinct tuples of <= in_chans entries; the cache is bounded); per-step random
         lists (the dropout_tokens_hcs keep list, ~1.5k entries, new every step) are built as temporaries."""
+        if isinstance(values, _DevList):
+            values = values.t
+        if torch.is_tensor(values):  # already on the device (the HCS subset is drawn there and never visits the host)
+            return values.to(device=device, dtype=dtype)
         if not cache:
             return torch.tensor(list(values), dtype=dtype, device=device)
         key = (tuple(values), dtype, str(device))
@@ -495,15 +574,21 @@ class DiChaViT(nn.Module):
                 else:
                     e = F.normalize(channel_embed.detach(), p=2, dim=-1)
                     cos = (e @ e.t())[anchor]  # :169-174
-                if mode == "lowest_cosine":
-                    ind = torch.topk(cos, k=Cin_new, largest=False).indices.cpu().tolist()
-                elif mode == "highest_cosine":
-                    ind = torch.topk(cos, k=Cin_new, largest=True).indices.cpu().tolist()
-                elif mode in ("lowest_cosine_prob", "lowest_cosine_prob_proj"):
-                    prob = F.softmax((1 - cos) / cfg.hcs_sampling_temp, dim=-1)  # :194-196
-                    ind = torch.multinomial(prob, Cin_new, replacement=False).cpu().tolist()  # :199
-                else:
-                    raise ValueError(f"Invalid hcs_sampling: '{mode}'")  # :206
+                ind = hcs_pick(cos, Cin_new, mode, cfg.hcs_sampling_temp)
+                if self.hcs_on_device and cos.is_cuda:
+                    # The reference moves `ind` to the host here (.cpu().tolist(), :178/184/200) — one synchronisation per training step.
+                    # Nothing downstream needs the VALUES on the host: the sequence length depends on Cin_new alone (drawn on the host
+                    # above), every use of the subset is a device gather (channel_embed rows, proxy rows, the tokeniser's channel index,
+                    # the input affine), and the pick histogram is counted on the device and read lazily (_PickCounter).  Same RNG draws in
+                    # the same order, same subset, no host round trip.
+                    ind = hcs_force_anchor(ind, anchor)  # :201-202
+                    ch_t = self._index_tensor(cur_channels, torch.int64, cos.device)
+                    picked = ch_t[ind]
+                    if hasattr(pe, "counter"):
+                        pe.counter.add_device(picked, int(self.feature_extractor.in_chans))  # :214-216
+                    return _DevList(picked, Cin_new), _DevList(ind, Cin_new)  # positions = ind: the mapper lists distinct ids
+                ind = ind.cpu().tolist()
+                self.host_syncs += 1
                 if anchor not in ind:  # :201-202
                     ind[-1] = anchor
             picked = [cur_channels[i] for i in ind]
@@ -920,6 +1005,16 @@ class DiChaViT(nn.Module):
             if side is not None:
                 held.append(dict(L))  # the side stream may still be reading the saved activations
             L.clear()
+            if self.wgrad_scratch_release:
+                # Everything in `held` — older layers' dz / dqkv / dxb and this layer's saved activations — has had its LAST reader queued
+                # (the block's weight-gradient launches above — grouped or one by one, they are all in their queue by now).  On one stream that is enough to hand the memory back; with the second stream
+                # the caching allocator is told who still reads it (record_stream: the block is reused only after that stream's work
+                # queued so far has completed).  Peak scratch then is what the second stream lags behind, not depth x 0.7 GB.
+                for t in held:
+                    for v in (t.values() if isinstance(t, dict) else (t,)):
+                        if side is not None and torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(side)
+                held.clear()
             if dp is not None:
                 if side is not None:
                     # hand the bucket over FROM the side stream: the collective is ordered after the stream it is issued on, and the
@@ -1031,7 +1126,7 @@ class DiChaViT(nn.Module):
         idx = list(range(Cin))
         if self.training and pe.enable_sample:  # :127
             cur_channels, idx = self._sample_channels(chunk_name, cur_channels, channel_embed, x)
-            channel_embed = channel_embed[idx]  # :136/212
+            channel_embed = channel_embed[idx.t if isinstance(idx, _DevList) else idx]  # :136/212
         if pe.use_channelvit_channels and (not self.training) and (training_chunks is not None):  # :219
             channel_embed = self._eval_channel_embed(chunk_name, training_chunks, new_channel_init)
         C = len(idx)
@@ -1089,11 +1184,15 @@ class DiChaViT(nn.Module):
             # linear in the statistics: mean_b(gamma_s * (+-)pos_b / pos_cnt + gamma_d * neg_b / neg_cnt) (+ gamma_s) = sum_b stats_b . w + c0 with
             # w = (+-gamma_s / pos_cnt, gamma_d / neg_cnt) / B — four launches forward and two backward instead of ~20 on a [B, 2] tensor
             sgn = 1.0 if cfg.reverse_pos_pairs else -1.0
-            key = (stats.shape[0], C, n, str(stats.device))
+            key = (stats.shape[0], C, n, str(stats.device), float(cfg.gamma_s), float(cfg.gamma_d), bool(cfg.reverse_pos_pairs))  # everything w depends on
             w = self._stats_w.get(key)
             if w is None:
-                w = self._stats_w[key] = torch.tensor([sgn * cfg.gamma_s / pos_cnt, cfg.gamma_d / neg_cnt], dtype=torch.float32,
-                                                      device=stats.device) / stats.shape[0]
+                # filled on the device (two fill kernels, once per key): torch.tensor(list, device=...) is a synchronising host-to-device
+                # copy, and with HCS a new channel count — a new key — can turn up at any step
+                w = torch.empty(2, dtype=torch.float32, device=stats.device)
+                w[0:1].fill_(sgn * cfg.gamma_s / pos_cnt / stats.shape[0])
+                w[1:2].fill_(cfg.gamma_d / neg_cnt / stats.shape[0])
+                self._stats_w[key] = w
             return _LinearStatsLossFn.apply(stats, w, 0.0 if cfg.reverse_pos_pairs else float(cfg.gamma_s))
         pos = stats[:, 0] / pos_cnt
         neg = stats[:, 1] / neg_cnt

@@ -87,6 +87,8 @@ class DataParallel:
         self.buckets_launched = 0
         self.bytes_reduced = 0
         self._callback_queued = False
+        self._queued_in_task = -1   # autograd graph-task id of the backward pass that queued the callback
+        self._poisoned = None       # set when a backward pass failed at world > 1: the ranks' collective sequences no longer match
         model._dp = self
         self._hooks = []
         self._hooked = set()
@@ -143,27 +145,52 @@ class DataParallel:
         if self._callback_queued:
             return
         self._callback_queued = True
+        self._queued_in_task = self._current_task()
         torch.autograd.Variable._execution_engine.queue_callback(self._engine_callback)
 
     def _engine_callback(self) -> None:
         self._callback_queued = False
         self.finalize()
 
+    @staticmethod
+    def _current_task() -> int:
+        """Id of the autograd graph task this thread is executing (-1 outside a backward pass)."""
+        f = getattr(torch._C, "_current_graph_task_id", None)
+        return int(f()) if f is not None else -1
+
     def begin_forward(self) -> None:
         """Called by the model at the start of every training forward.  The autograd engine skips its end-of-backward callbacks when a
         backward pass raises (HIP error, out of memory, an exception in user code), which would leave `_callback_queued` set for good —
         no later backward would queue finalize() and torch optimisers would read gradients whose all-reduces are still in flight.
-        A set flag here means exactly that: drain what the failed pass left behind and start clean."""
-        if self._callback_queued:
-            self._callback_queued = False
-            self._pending = None
-            self._deferred = []
-            for w, _, _ in self._works:
-                try:
-                    w.wait()
-                except Exception:  # the failed pass's collectives may have failed with it
-                    pass
-            self._works.clear()
+
+        A set flag is NOT proof of that by itself: a training forward that legitimately runs INSIDE a backward pass (activation
+        checkpointing's recompute, a forward called from a hook after the callback was queued) sees it too.  Such a forward runs while an
+        autograd graph task is executing on this thread — then nothing is touched.  Outside any backward pass a set flag does mean the pass
+        that set it never finished:
+          * world size 1: nothing is shared with anybody; drain what the failed pass left behind and start clean;
+          * world size > 1: this rank cannot repair it alone — its peers have issued every bucket of that step, so this rank's next
+            collectives would pair with the wrong buckets or sizes (an RCCL hang or silent corruption).  The reducer is marked poisoned
+            and this and every later forward raise until the job is restarted (what torch DDP's reducer does after a failed backward)."""
+        if self._poisoned is not None:
+            raise RuntimeError(self._poisoned)
+        if not self._callback_queued:
+            return
+        if self._current_task() != -1:
+            return  # a forward inside a running backward pass: the callback of that pass is still going to run
+        if self.world > 1:
+            self._poisoned = ("diverse_channel_vit_amd.DataParallel: a backward pass did not finish on this rank (it raised before the autograd "
+                              "engine ran the end-of-backward callback).  The ranks' all-reduce sequences no longer match; gradient exchange "
+                              "cannot be resynchronised from one rank — restart the job.")
+            raise RuntimeError(self._poisoned)
+        self._callback_queued = False
+        self._pending = None
+        self._deferred = []
+        for w, _, _ in self._works:
+            try:
+                w.wait()
+            except Exception:  # the failed pass's collectives may have failed with it
+                pass
+        self._works.clear()
 
     # ---- small parameters outside the encoder node --------------------------------------------------
     def hook_misc_params(self) -> None:

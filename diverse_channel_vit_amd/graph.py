@@ -34,6 +34,7 @@ class GraphedTrainStep:
         self.lam = extra_loss_lambda
         self.warmup = warmup
         self.graph = None
+        self.capture_two_streams = False  # see _capture
         self.static_x = self.static_y = self.static_loss = self.static_out = self.static_extra = None
 
     def _eager(self):
@@ -58,8 +59,19 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         self.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g):
-            self.static_loss = self._eager()
+        # One stream inside the capture.  With the weight-gradient GEMMs on a second stream every hand-over between the streams becomes an
+        # edge between two branches of the graph, which the replay realises as dependency packets in BOTH queues — the waits the eager
+        # step keeps out of its compute queue (per-layer scratch).  Measured at the headline shape (round 4, one box, gpurun_out/r4f):
+        # eager 35.38 (one stream) / 35.33 ms (two); captured 35.21 ms (one) / 35.94 ms (two).  The captured step therefore runs on one
+        # stream (0.4 % faster than the best eager form instead of 1.7 % slower); `capture_two_streams = True` keeps the model's setting.
+        two = self.model.wgrad_stream
+        if not self.capture_two_streams:
+            self.model.wgrad_stream = False
+        try:
+            with torch.cuda.graph(g):
+                self.static_loss = self._eager()
+        finally:
+            self.model.wgrad_stream = two
         self.graph = g
 
     def __call__(self, x, y):

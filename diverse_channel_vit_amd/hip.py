@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCV_LIB", os.path.join(_HERE, "libdcv_hip.so"))  # DCV_LIB: A/B builds of the same ABI
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RESID_F32, EPI_PLAIN_BF16, EPI_GELU_BWD_BF16, EPI_PATCH = range(6)
-TILE_AUTO, TILE_NARROW, TILE_WIDE = range(3)  # include/dcv.h DCV_TILE_*
+TILE_AUTO, TILE_NARROW, TILE_WIDE, TILE_PAIR = range(4)  # include/dcv.h DCV_TILE_*
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
@@ -179,6 +179,7 @@ def _req(t: torch.Tensor, dtype, name: str):
 # (device, stream), grown on demand; kernels on one stream run in order, so they can share it.
 _deterministic = os.environ.get("DCV_DETERMINISTIC", "1") not in ("0", "", "false", "False")
 _det_ws = {}
+_det_ws_retired = []  # outgrown workspaces, kept alive (see _workspace)
 
 
 def set_deterministic(on: bool = True) -> bool:
@@ -196,6 +197,11 @@ def _workspace(n_floats: int, like: torch.Tensor) -> torch.Tensor:
     key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream)
     ws = _det_ws.get(key)
     if ws is None or ws.numel() < n_floats:
+        if ws is not None:
+            # never freed: a captured HIP graph (graph.GraphedTrainStep) replays launches that carry the OLD workspace's address; handing
+            # that block back to the allocator would let replays write partial tiles into somebody else's memory.  Growth is
+            # rare (the first steps of a run) and the sizes small (<= 50 MB each).
+            _det_ws_retired.append(ws)
         ws = torch.empty(max(int(n_floats), 1 << 20), dtype=torch.float32, device=like.device)
         _det_ws[key] = ws
     return ws
@@ -220,7 +226,7 @@ def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T
     lib = load()
 
     def describe():
-        kind = "gemm_nt384" if lib.dcv_gemm_nt_pick(M, N, K, epilogue, tile) == TILE_WIDE else "gemm_nt"
+        kind = {TILE_WIDE: "gemm_nt384", TILE_PAIR: "gemm_nt_pair"}.get(lib.dcv_gemm_nt_pick(M, N, K, epilogue, tile), "gemm_nt")
         nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (_EPI_OUT_BYTES[epilogue] + _EPI_AUX_BYTES[epilogue])
         return f"{kind}_kernel<{epilogue}>", f"M{M} N{N} K{K}", 2.0 * M * N * K, None, nbytes
 

@@ -51,6 +51,7 @@ int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, in
 #define DCV_TILE_AUTO 0
 #define DCV_TILE_NARROW 1
 #define DCV_TILE_WIDE 2
+#define DCV_TILE_PAIR 3 /* dcv_gemm_nt_ex only: 128 x 128 tiles by four-wave workgroups, TWO per CU (one stores while the other computes) */
 /* dcv_gemm_nt with its launch controls as arguments: both kernels are persistent (one workgroup per CU walks the output
  * tiles, several rounds when there are more tiles than workgroups); grid_cap > 0 caps the number of workgroups (0 = one per
  * CU of the current device) — the data-parallel backward leaves CUs to RCCL's kernels this way. */

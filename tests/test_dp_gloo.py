@@ -312,6 +312,101 @@ def test_begin_forward_recovers_after_a_failed_backward():
         dist.destroy_process_group()
 
 
+def test_begin_forward_inside_a_running_backward_is_left_alone():
+    """a training forward that legitimately runs INSIDE a backward pass (a checkpoint recompute, a forward called from a
+    hook after the callback was queued) sees `_callback_queued` set; that is not a failed pass and nothing may be dropped — the in-flight
+    buckets of the running pass must still be waited for by its own callback."""
+    import torch.distributed as dist
+    from diverse_channel_vit_amd.dp import DataParallel
+
+    class Stub:
+        _dp = None
+
+        def parameters(self):
+            return []
+
+        def _enc_param_list(self):
+            return []
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        dp = DataParallel(Stub(), force_collectives=True)
+        arena = torch.ones(8)
+        seen = {}
+
+        class Probe(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                return x * 1.0
+
+            @staticmethod
+            def backward(ctx, g):
+                dp.queue_finalize()                 # what the model's node does first
+                dp.grad_ready(arena, 0, 8)          # a bucket of this pass is in flight / pending
+                assert dp._callback_queued
+                dp.begin_forward()                  # the recompute's forward
+                seen["queued_after"] = dp._callback_queued
+                seen["task"] = DataParallel._current_task()
+                return g
+
+        x = torch.ones(3, requires_grad=True)
+        Probe.apply(x).sum().backward()
+        assert seen["task"] != -1, "this torch build does not expose the running graph task: the guard cannot work"
+        assert seen["queued_after"] is True           # left alone inside the pass ...
+        assert dp._callback_queued is False           # ... and the pass's own callback ran at its end
+        assert not dp._works and dp._pending is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _poison_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        from diverse_channel_vit_amd.dp import DataParallel
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        class Stub:
+            _dp = None
+
+            def parameters(self):
+                return []
+
+            def _enc_param_list(self):
+                return []
+
+        dp = DataParallel(Stub())
+        dp._callback_queued = True  # a backward pass queued the callback and then raised on this rank
+        msgs = []
+        for _ in range(2):          # this forward AND every later one
+            try:
+                dp.begin_forward()
+                msgs.append("no error")
+            except RuntimeError as e:
+                msgs.append(str(e))
+        q.put((rank, msgs))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, ["worker failed: %r" % (e,)]))
+
+
+def test_failed_backward_poisons_the_reducer_at_world_size_two():
+    """ADVICE r3 (medium): at world size > 1 a rank cannot repair a failed backward alone (its peers issued every bucket of that step);
+    the reducer must refuse to continue instead of resetting silently."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_poison_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, world)
+    for p in procs:
+        p.join(60)
+    for rank, msgs in res:
+        assert len(msgs) == 2 and all("did not finish" in m and "restart" in m for m in msgs), (rank, msgs)
+
+
 def test_merge_views_of_one_arena():
     """DataParallel._merge_views (overlap=False): neighbouring 1-D views of one arena become ONE view over their union, whatever order they
     arrive in; views that do not touch stay separate; tensors that are not contiguous 1-D views of a base are returned as they are."""

@@ -93,3 +93,34 @@ def test_special_inits_and_constants():
     assert E2.std().item() == pytest.approx(0.02, rel=0.05)
     Pm = model2.feature_extractor.patch_embed.channel_emb_proxies.detach().double()
     assert torch.allclose(Pm @ Pm.t(), torch.eye(Pm.shape[0], dtype=torch.float64), atol=1e-5)
+
+
+def test_hcs_draws_of_the_reference_reproduced_by_the_product_sampler():
+    """the HCS subset now stays on the device (no .cpu() per step).  The draw itself — python RNG for the subset size and
+    the anchor, torch.multinomial / topk on the anchor's cosine row, the anchor forced in — is the product's `hcs_pick` / `hcs_force_anchor`
+    on whatever device the embeddings live; replayed here on the CPU with the seeds recorded in tests/golden/hcs.npz it reproduces the
+    reference's own picks EXACTLY for every recorded draw (torch's CPU generator is the one the reference drew from; a GPU cannot reproduce
+    a CPU multinomial stream, which is why the GPU parity tests inject the subset)."""
+    import random
+    import torch.nn.functional as F
+    from diverse_channel_vit_amd.dichavit import hcs_pick, hcs_force_anchor
+    from oracle import dichavit_oracle as orc  # test infrastructure: the seeded parameter generator the goldens were built from
+    meta, a = load_golden("hcs")
+    shapes = orc.state_shapes(meta["cfg"], meta["n_channels"], meta["img"], meta["num_classes"])
+    E = orc.make_state(shapes, meta["seed"])["feature_extractor.patch_embed.channel_embed.weight"]
+    cur = meta["mapper"]["train"]
+    checked = 0
+    for k, d in enumerate(meta["draws"]):
+        if d["mode"] == "none":
+            continue
+        rng = random.Random(d["pyseed"])
+        torch.manual_seed(d["tseed"])
+        Cin_new = rng.randint(1, len(cur))
+        anchor = rng.randint(0, len(cur) - 1)
+        e = F.normalize(E[cur].detach(), p=2, dim=-1)
+        cos = (e @ e.t())[anchor]
+        ind = hcs_force_anchor(hcs_pick(cos, Cin_new, d["mode"], d["temp"]), anchor)
+        picked = [cur[i] for i in ind.tolist()]
+        assert picked == a[f"d{k}_picked"].tolist(), (k, d, picked, a[f"d{k}_picked"].tolist())
+        checked += 1
+    assert checked >= 5

@@ -94,22 +94,26 @@ HEADLINE_M = 64 * 1569
 HEADLINE_NK = [(1152, 384), (384, 384), (1536, 384), (384, 1536)]
 
 
-@pytest.mark.parametrize("tile", ["narrow", "wide"])
+_NT_TILES = {"narrow": 1, "wide": 2, "pair": 3}  # hip.TILE_*; pair = 128 x 128 tiles by four-wave workgroups, two per CU (round 4)
+
+
+@pytest.mark.parametrize("tile", ["narrow", "wide", "pair"])
 @pytest.mark.parametrize("N,K", HEADLINE_NK)
 def test_gemm_nt_headline_shapes_multi_round(hip, N, K, tile):
-    """(i) of the persistence coverage: the exact shapes of bench.py's step, every epilogue, both tile shapes, many rounds
-    per workgroup, a partial last M tile (100 416 = 392 x 256 + 64)."""
-    _check_gemm_nt(hip, HEADLINE_M, N, K, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE)
+    """(i) of the persistence coverage: the exact shapes of bench.py's step, every epilogue, all three tile shapes, many rounds
+    per workgroup, a partial last M tile (100 416 = 392 x 256 + 64 = 784 x 128 + 64)."""
+    _check_gemm_nt(hip, HEADLINE_M, N, K, tile=_NT_TILES[tile])
 
 
 @pytest.mark.parametrize("grid_cap", [4, 8, 248])
 @pytest.mark.parametrize("M,N,K,tile", [(5000, 384, 384, "narrow"), (5000, 1152, 384, "wide"), (5100, 384, 1536, "wide"),
-                                        (5100, 1536, 384, "narrow"), (66000, 384, 384, "wide"), (33000, 1152, 384, "narrow")])
+                                        (5100, 1536, 384, "narrow"), (66000, 384, 384, "wide"), (33000, 1152, 384, "narrow"),
+                                        (5000, 1152, 384, "pair"), (5100, 392, 1536, "pair"), (33000, 384, 64, "pair")])
 def test_gemm_nt_forced_small_grids(hip, M, N, K, tile, grid_cap):
     """(ii): few workgroups on a small problem, so that total tiles > grid: long tile walks (up to 60 rounds at 4 workgroups),
     a partial last round, the `stores_behind` waits and the epilogue-overlapped prefetch all execute.  248 = the
     data-parallel backward's grid (CUs minus the ones left to RCCL); the last two shapes have more tiles than that."""
-    _check_gemm_nt(hip, M, N, K, tile=hip.TILE_NARROW if tile == "narrow" else hip.TILE_WIDE, grid_cap=grid_cap)
+    _check_gemm_nt(hip, M, N, K, tile=_NT_TILES[tile], grid_cap=grid_cap)
 
 
 def test_gemm_nt_random_shapes_tiles_and_grids(hip):
@@ -123,10 +127,11 @@ def test_gemm_nt_random_shapes_tiles_and_grids(hip):
         wide = bool(rng.randint(0, 2))
         N = 384 * int(rng.randint(1, 5)) if wide else 8 * int(rng.randint(1, 193))
         cap = int(rng.choice([0, 0, 1, 3, 7, 30, 200]))
-        try:
-            _check_gemm_nt(hip, M, N, K, tile=hip.TILE_WIDE if wide else hip.TILE_NARROW, grid_cap=cap)
-        except AssertionError as e:
-            raise AssertionError(f"M={M} N={N} K={K} wide={wide} grid_cap={cap}: {e}") from e
+        for t in ((hip.TILE_WIDE,) if wide else (hip.TILE_NARROW, hip.TILE_PAIR)):
+            try:
+                _check_gemm_nt(hip, M, N, K, tile=t, grid_cap=cap)
+            except AssertionError as e:
+                raise AssertionError(f"M={M} N={N} K={K} tile={t} grid_cap={cap}: {e}") from e
 
 
 def test_gemm_nt_auto_tile_rules(hip):

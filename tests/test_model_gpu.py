@@ -299,6 +299,48 @@ def test_hcs_subsets_parity(gpu_device):
     assert sorted(model.feature_extractor.patch_embed.counter.keys()) == sorted(a["d2_picked"].tolist())
 
 
+def test_hcs_subset_stays_on_the_device(gpu_device):
+    """VERDICT r3 item 7 / SURVEY 8f row 2: the reference's HCS branch moves the sampled subset to the host every step
+    (dichavit.py:178/184/200).  Here the draw (same python-RNG and torch-RNG calls in the same order) stays on the device: sequence length
+    from the host-drawn subset size, every use of the subset a device gather, picks counted on the device and read lazily.  Checked: three
+    training steps run with torch's sync debug mode set to "error" (any synchronising call raises); under the same seeds the legacy path
+    (hcs_on_device = False: .cpu() per step, counted in model.host_syncs) gives bit-identical logits and the same pick histogram."""
+    meta, _ = load_golden("hcs")
+    x, y = orc.make_batch(42, 3, 6, 32, 7)
+    xg, yg = x.to(gpu_device), y.to(gpu_device)
+    ce = torch.nn.CrossEntropyLoss()
+    res = {}
+    for on_dev in (False, True):
+        model, _ = build(meta, gpu_device)
+        model.cfg["hcs_sampling"], model.cfg["hcs_sampling_temp"] = "lowest_cosine_prob", 1000.0
+        model.hcs_on_device = on_dev
+        pe = model.feature_extractor.patch_embed
+        random.seed(17)
+        torch.manual_seed(23)
+        for _ in range(2):  # warm-up: arena, caches, index tensors
+            out, extra = model(xg, "train", None)
+            (ce(out, yg) + extra).backward()
+        pe.counter.clear()
+        torch.cuda.synchronize()
+        s0 = model.host_syncs
+        outs = []
+        if on_dev:
+            torch.cuda.set_sync_debug_mode("error")
+        try:
+            for _ in range(3):
+                model.zero_grad(set_to_none=True)
+                out, extra = model(xg, "train", None)
+                (ce(out, yg) + extra).backward()
+                outs.append(out.detach())
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        res[on_dev] = ([o.clone() for o in outs], dict(pe.counter), model.host_syncs - s0)
+    assert res[False][2] == 3 and res[True][2] == 0
+    assert res[False][1] == res[True][1] and sum(res[True][1].values()) >= 3
+    for a_, b_ in zip(res[False][0], res[True][0]):
+        assert a_.shape == b_.shape and torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("rounding", ["nearest", "stochastic"])
 def test_chammi_chunks_parity(gpu_device, rounding):
     """Three forward/backward passes with 3/4/5 channels (different sequence lengths), gradients
@@ -413,7 +455,8 @@ def _run_curve(gpu_device, name, stochastic):
 
 
 def _curve_report(tag, e, ref):
-    print(f"{tag} |err|: step0 {e[0]:.2e} max {e.max():.3e} mean {e.mean():.3e} tail20 max {e[-20:].max():.3e} (ref loss {ref[0]:.3f} -> {ref[-1]:.3f})")
+    print(f"{tag} |err|: step0 {e[0]:.2e} max {e.max():.3e} mean {e.mean():.3e} tail20 max {e[-20:].max():.3e} steps above 1e-3: {int((e > 1e-3).sum())} "
+          f"(ref loss {ref[0]:.3f} -> {ref[-1]:.3f})")
 
 
 def test_loss_curve_100_steps(gpu_device):
@@ -477,9 +520,12 @@ def test_loss_curve_headline_architecture_distinct_batches(gpu_device):
     the value stated below.  Bounds are FROZEN at round 4's values: a later build that exceeds them is a finding to explain, not a number to re-fit."""
     e_sr, ref = _run_curve(gpu_device, "curve100_jumpcp_s_b8", True)
     _curve_report("loss-curve headline bs8 distinct, stochastic", e_sr, ref)
-    assert e_sr.mean() <= 1e-3, e_sr.mean()
-    assert e_sr[-20:].max() <= 1e-3, e_sr[-20:].max()
-    assert e_sr.max() <= 5e-3, e_sr.max()
+    # measured in round 4 (deterministic mode, bit-reproducible on a build): step 0 2.90e-4, max 2.304e-3 (one step of the 100), mean 3.927e-4,
+    # largest of the last 20 steps 7.453e-4
+    assert e_sr.mean() <= 1e-3, e_sr.mean()             # north_star's criterion, on the mean ...
+    assert e_sr[-20:].max() <= 1e-3, e_sr[-20:].max()   # ... and on every one of the last 20 steps
+    assert e_sr.max() <= 2.8e-3, e_sr.max()             # the worst single step: frozen at 1.2 x round 4's 2.304e-3
+    assert int((e_sr > 1e-3).sum()) <= 15               # how many of the 100 steps exceed 1e-3 at all (printed above)
 
 
 @pytest.mark.parametrize("rounding", ["nearest", "stochastic"])
@@ -710,6 +756,63 @@ def test_fused_input_normalisation(gpu_device):
     with pytest.raises(ValueError):
         model(raw.to(gpu_device), "HPA")
 
+
+
+def test_grad_scaler_flow_of_the_reference_trainer(gpu_device):
+    """The reference's `use_amp` flow (trainer.py:861, 921-935; default off): scaler.scale(loss).backward(); scaler.unscale_(opt);
+    clip; scaler.step(opt); scaler.update() — driven through the hand-written backward, the gradient arena and HipAdamW (VERDICT r3 missing 5;
+    INTEGRATION.md claims it works).  The loss scale is a power of two, so every scaled gradient is the unscaled one times 2^k exactly (bf16
+    and fp32 share an exponent range): after unscale_ the step must retrace the plain flow BIT FOR BIT; and a step whose gradients overflow
+    must be skipped (parameters untouched, scale halved)."""
+    import diverse_channel_vit_amd as dcv
+    meta, _ = load_golden("so2sat_s")
+    ce = torch.nn.CrossEntropyLoss()
+    batches = [orc.make_batch(501 + i, 4, 18, 32, 17) for i in range(3)]
+    batches = [(x.to(gpu_device), y.to(gpu_device)) for x, y in batches]
+
+    def run(use_scaler):
+        model, _ = build(meta, gpu_device)
+        model.stochastic_weight_rounding = False
+        opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.04, model=model)
+        scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12, growth_interval=1000) if use_scaler else None
+        losses = []
+        for s in range(3):
+            x, y = batches[s]
+            opt.zero_grad()
+            out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            loss = ce(out, y) + extra
+            if scaler is None:
+                loss.backward()
+                dcv.clip_grad_norm_(model, 5.0)
+                opt.step()
+            else:
+                scaler.scale(loss).backward()
+                scaler.unscale_(opt)
+                dcv.clip_grad_norm_(model, 5.0)
+                scaler.step(opt)
+                scaler.update()
+            losses.append(loss.item())
+        return model, opt, scaler, losses
+
+    m0, _, _, l0 = run(False)
+    m1, opt1, scaler, l1 = run(True)
+    assert l0 == l1, (l0, l1)
+    for (n0, p0), (n1, p1) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert n0 == n1 and torch.equal(p0.detach(), p1.detach()), n0
+    assert scaler.get_scale() == 2.0 ** 12
+    # an overflowing step: the scaler must see the inf in the arena's gradient views and skip the optimiser step
+    before = [p.detach().clone() for p in m1.parameters()]
+    x, y = batches[0]
+    opt1.zero_grad()
+    out, extra = m1(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    loss = ce(out, y) + extra
+    scaler.scale(loss * float("inf")).backward()
+    scaler.unscale_(opt1)
+    scaler.step(opt1)
+    scaler.update()
+    assert scaler.get_scale() == 2.0 ** 11
+    for b, p in zip(before, m1.parameters()):
+        assert torch.equal(b, p.detach())
 
 
 def test_clipping_checkpoint_resume_parity(gpu_device, tmp_path):

@@ -80,7 +80,7 @@ for rnd in range(int(os.environ.get("AB_ROUNDS", 12))):
             outs[i] = (o.float().clone(), dqkv.float().clone())
 for i, l in enumerate(libs):
     if id(handles[i]) in errw:
-        print("  err / slow-path entries / spins / entries by iteration:", errw[id(handles[i])]())
+        print("  error word of the one-pass backward:", errw[id(handles[i])]()[0])
     t = {k: res[(i, k)] for k in KEYS if res[(i, k)]}
     same = "" if i == 0 else f"  max|dO-ref| {float((outs[i][0] - outs[0][0]).abs().max()):.3g} max|dqkv-ref| {float((outs[i][1] - outs[0][1]).abs().max()):.3g}"
     print(f"{os.path.basename(l):40s} " + "  ".join(f"{k} {np.median(v):7.1f} (min {min(v):7.1f})" for k, v in t.items()) +

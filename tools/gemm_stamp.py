@@ -1,5 +1,5 @@
 """Where a persistent workgroup of the 256 x 384 GEMM spends its cycles: k-loop (operand DMA + MFMA) vs epilogue (slab transposition,
-fused op, stores).  Needs the diagnostic build: python -c "from diverse_channel_vit_amd import _build; _build.build_variant('stamp', ['DCV_STAMP=1'])"
+fused op, stores).  Needs the diagnostic build: python -c "from diverse_channel_vit_amd import _build; _build.build_variant('stamp', ['DCV_STAMP=1'], instrumented=('gemm.hip',))"
 then  DCV_LIB=diverse_channel_vit_amd/libdcv_hip_stamp.so python tools/gemm_stamp.py"""
 import os, sys
 import numpy as np

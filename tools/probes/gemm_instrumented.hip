@@ -1,3 +1,6 @@
+// DIAGNOSTIC TWIN of diverse_channel_vit_amd/csrc/gemm.hip (snapshot of round 4's kernels): the same kernels WITH the measurement harness — cycle stamps
+// (DCV_STAMP), timing-only ablations (DCV_GABL / DCV_TABL), the L2-resident A operand (DCV_AWRAP), staggered starts (DCV_STAGGER) and the settled A/B switches.
+// Never part of the product library: built only by _build.build_variant(name, defines, instrumented=('gemm.hip',)) into libdcv_hip_<name>.so.
 // bf16 MFMA GEMMs for the DiChaViT encoder (gfx950).
 //
 //  gemm_nt : C[M,N] = A[M,K] . W[N,K]^T   (both operands K-contiguous)  + fused epilogues.
@@ -13,8 +16,7 @@
 // gemm_tn: 128x128 register-staged kernel (4 waves) and the 384x128 LDS-DMA ring kernel (8 waves).
 #include <atomic>
 #include <type_traits>
-#include "dcv_common.hpp"
-#include "../../include/dcv.h"
+#include "dcv_common.hpp"  // found through -I csrc (build_variant)
 
 namespace {
 
@@ -47,6 +49,9 @@ __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& e) {
     const float erf_abs = 1.0f - poly * e;
     cdf = 0.5f * (1.0f + copysignf(erf_abs, z));
 }
+#ifndef DCV_GELU_PK
+#define DCV_GELU_PK 1  // fc1 epilogue on two elements at a time: 225-227 us against 232-243 (profiles/r02_x8_*); 0 = the scalar form
+#endif
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // the same arithmetic on two elements at a time (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32; rcp and exp2 stay scalar)
 __device__ __forceinline__ void gelu_parts2(f32x2_t z, f32x2_t& g, f32x2_t& gp) {
@@ -80,14 +85,31 @@ __device__ __forceinline__ void unpack8_bf16(uint4 u, float* v) {
 // Streaming (non-temporal) 16-byte accesses for data this kernel touches exactly once — the output tile, the residual
 // and the saved pre-activation: they must not evict the A row-panel, which the other column tiles of the same XCD are
 // about to re-read, from the 4 MB L2 (PMC before: fc1 fetched its 77 MB A operand 3.3 times).
+#ifndef DCV_NT_STREAM
+#define DCV_NT_STREAM 1
+#endif
+#ifndef DCV_RESID_LD_STREAM
+#define DCV_RESID_LD_STREAM 0
+#endif
+#ifndef DCV_RESID_ST_STREAM
+#define DCV_RESID_ST_STREAM 0
+#endif
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st128_stream(void* p, uint4 v) {
+#if DCV_NT_STREAM
     u32x4_t x = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(x, reinterpret_cast<u32x4_t*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
 }
 __device__ __forceinline__ uint4 ld128_stream(const void* p) {
+#if DCV_NT_STREAM
     u32x4_t x = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return make_uint4(x.x, x.y, x.z, x.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
 }
 __device__ __forceinline__ void load8_f32_stream(const float* p, float* v) {
     uint4 a = ld128_stream(p), b = ld128_stream(p + 4);
@@ -118,7 +140,11 @@ __device__ __forceinline__ void epi_aux8(const GemmNtArgs& a, int m, int n, floa
         // residual is read from aux when given (out-of-place keeps the layer input alive for the LayerNorm backward
         // at no extra traffic), else the output is updated in place
         const float* rsd = a.aux ? (const float*)a.aux + (size_t)m * a.ldaux + n : (const float*)a.out + (size_t)m * a.ldo + n;
+#if DCV_RESID_LD_STREAM
+        load8_f32_stream(rsd, x);
+#else
         load8_f32(rsd, x);
+#endif
     } else if constexpr (EPI == DCV_EPI_GELU_BWD_BF16) {
         unpack8_bf16(ld128_stream((const bf16_t*)a.aux + (size_t)m * a.ldaux + n), x);
     } else if constexpr (EPI == DCV_EPI_PATCH) {
@@ -143,6 +169,7 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
         // out = GELU'(z), out2 = GELU(z), z = acc + bias in fp32: the backward then only multiplies (the first version saved z
         // and recomputed the erf / exp in the backward epilogue, ~45 % of that kernel's time); cdf and exp(-z^2/2) are shared
         float gp[8];
+#if DCV_GELU_PK
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
             const f32x2_t z = {v[e] + bz[e], v[e + 1] + bz[e + 1]};
@@ -151,12 +178,26 @@ __device__ __forceinline__ void epi_store8(const GemmNtArgs& a, int m, int n, fl
             v[e] = g2.x; v[e + 1] = g2.y;
             gp[e] = gp2.x; gp[e + 1] = gp2.y;
         }
+#else
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float z = v[e] + bz[e];
+            float cdf, ex;
+            gelu_parts(z, cdf, ex);
+            v[e] = z * cdf;
+            gp[e] = cdf + z * 0.39894228040143268f * ex;
+        }
+#endif
         st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(gp));
         st128_stream((bf16_t*)a.out2 + (size_t)m * a.ldo2 + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_BIAS_RESID_F32) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bz[e] + x[e];
+#if DCV_RESID_ST_STREAM
+        store8_f32_stream((float*)a.out + (size_t)m * a.ldo + n, v);
+#else
         store8_f32((float*)a.out + (size_t)m * a.ldo + n, v);
+#endif
     } else if constexpr (EPI == DCV_EPI_PLAIN_BF16) {
         st128_stream((bf16_t*)a.out + (size_t)m * a.ldo + n, pack8_bf16(v));
     } else if constexpr (EPI == DCV_EPI_GELU_BWD_BF16) {
@@ -340,8 +381,29 @@ __device__ __forceinline__ void nt_load_bias(const GemmNtArgs& a, int n_w, int r
 // auxiliary loads of its epilogue, then the NEXT tile's first two ring stages, and only then applies the fused op and stores —
 // straight from the accumulators (register epilogue above; rounds 1-2 went through wave-private LDS slabs), with no workgroup
 // barrier — so the store tail and the GELU arithmetic overlap the next tile's operand streaming.
+#ifndef DCV_TABL
+#define DCV_TABL 0  // gemm_tn timing-only ablations: 1 = no atomic epilogue, 2 = no MFMA / transposed reads
+#endif
+#ifndef DCV_STAMP
+#define DCV_STAMP 0
+#endif
+#ifndef DCV_GABL
+#define DCV_GABL 0  // timing-only ablations: 1 = no epilogue, 2 = no MFMA/LDS reads, 3 = no operand DMA
+#endif
+#ifndef DCV_AWRAP
+#define DCV_AWRAP 0  // timing-only probe: the A operand's rows wrap to the first DCV_AWRAP rows (A stays L2-resident; outputs are wrong)
+#endif
 #ifndef DCV_N3_EARLY_AT
 #define DCV_N3_EARLY_AT 11  // gemm_nt384_kernel: waves 0-3 issue their DMA pieces behind MFMA step N of the stage (11 = between the two k-steps), waves 4-7 at the top; -1: all at the top.  Stamps (profiles/r03_x1_*): with all eight waves issuing first the matrix pipe idled ~640 cycles per stage (80 pieces x 16 TA cycles, older waves served first); -4 ... -8 % on the k-loop-heavy shapes
+#endif
+#ifndef DCV_STAGGER
+#define DCV_STAGGER 0  // probe: every other workgroup of an XCD starts DCV_STAGGER x 8128 cycles late
+#endif
+#ifndef DCV_READ_FIRST
+#define DCV_READ_FIRST 1  // gemm_nt384_kernel: a stage's first fragment reads are issued BEFORE the next stage's ten DMA pieces (-2 %; the narrow kernel and gemm_tn384 measured slower / equal with it)
+#endif
+#ifndef DCV_DMA_SPLIT
+#define DCV_DMA_SPLIT 1  // gemm_nt_kernel: the two waves of a SIMD issue their DMA pieces at different points of a stage (0: all at the top)
 #endif
 constexpr int NT_BM = 256, NT_BN = 128, NT_BK = 64, NT_STAGES = 3;
 constexpr int NT_A_BYTES = NT_BM * NT_BK * 2, NT_W_BYTES = NT_BN * NT_BK * 2, NT_STAGE_BYTES = NT_A_BYTES + NT_W_BYTES;  // 48 KB
@@ -369,7 +431,11 @@ __device__ __forceinline__ void nt_tile_setup(const GemmNtArgs& a, int L, int ti
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int row = 32 * wave + 8 * q + (lane >> 3);
+#if DCV_AWRAP
+        t.gA[q] = a.A + (size_t)(min(t.m0 + row, a.M - 1) % DCV_AWRAP) * a.lda + (((lane & 7) ^ swz64n(row)) * 8);
+#else
         t.gA[q] = a.A + (size_t)min(t.m0 + row, a.M - 1) * a.lda + (((lane & 7) ^ swz64n(row)) * 8);
+#endif
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -379,12 +445,14 @@ __device__ __forceinline__ void nt_tile_setup(const GemmNtArgs& a, int L, int ti
 }
 
 __device__ __forceinline__ void nt_issue(const NtTile& t, int kt, unsigned stage_base, unsigned dmaA, unsigned dmaW) {
+#if DCV_GABL != 3
     glds16(t.gA[0] + kt * NT_BK, stage_base + dmaA);
     glds16(t.gA[1] + kt * NT_BK, stage_base + dmaA + 1024);
     glds16(t.gA[2] + kt * NT_BK, stage_base + dmaA + 2048);
     glds16(t.gA[3] + kt * NT_BK, stage_base + dmaA + 3072);
     glds16(t.gW[0] + kt * NT_BK, stage_base + dmaW);
     glds16(t.gW[1] + kt * NT_BK, stage_base + dmaW + 1024);
+#endif
 }
 
 template <int EPI>
@@ -432,6 +500,9 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(bz[e]));
     }
 
+#if DCV_STAMP
+    unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = clock64();
+#endif
     for (;;) {
         f32x4 acc[4][4];  // wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16
 #pragma unroll
@@ -455,19 +526,26 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();  // everyone's stage g landed; everyone is done reading buffer (g-1)%3
+#if DCV_DMA_SPLIT
             // The two waves of a SIMD (w and w + 4) issue their 6 DMA pieces at different times — one at the top of the stage, the
             // other between its two k-steps — so that one of them is always feeding the matrix pipe (a piece costs 60-180 issue cycles,
             // six of them about as much as the stage's 32 MFMAs): -4 .. -7 % on every shape (profiles/r02_x10_*).  The per-wave issue
             // ORDER is unchanged, so the counted vmcnt waits hold; the ring is three deep, the late pieces still have a full stage to land.
             if (!late && kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+#else
+            if (kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+#endif
             const char* st = smem + (g % NT_STAGES) * NT_STAGE_BYTES;
+#if DCV_GABL != 2
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {  // two k-steps of 32
+#if DCV_DMA_SPLIT
                 if (ks == 1) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (late && kt + 2 < nk) nt_issue(cur, kt + 2, smem_base + ((g + 2) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
                 bf16x8 af[4], wf[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {  // rows 16 i + r16 of the wave's A / W block: swz64n(16 i + r16) = ((r16 >> 1) & 7) for every i
@@ -480,15 +558,33 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);  // operands swapped: the tile comes out transposed (register epilogue)
             }
+#else
+            asm volatile("" ::"v"(st));
+#endif
         }
         // no barrier here: the epilogue reads no LDS, and the two ring buffers the prefetch below fills (stages g-3 and g-2 of this
         // workgroup's stream) were last read before barriers every wave has already passed
+#if DCV_STAMP
+        const unsigned long long st_t1 = clock64();
+        st_loop += st_t1 - st_t0;
+#endif
 
         // ---- epilogue of `cur` straight from the accumulators, overlapped with the first two stages of the next tile ----
         const int Ln = Lnext;
         const bool has_next = Ln >= 0;
         Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
         const bool full = (cur.m0 + NT_BM <= a.M) && (cur.n0 + NT_BN <= a.N) && (EPI != DCV_EPI_PATCH);
+#if DCV_GABL == 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        if (has_next) {
+            nt_tile_setup(a, Ln, tiles_n, wave, lane, nxt);
+            nt_issue(nxt, 0, smem_base + (g % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+            if (nk > 1) nt_issue(nxt, 1, smem_base + ((g + 1) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
+        }
+#else
         // all auxiliary loads first (they are then OLDER than the prefetch DMAs, so hipcc's own waits for them never wait for the
         // prefetch), then the next tile's bias and first two stages, then the fused op and the stores
         nt_epilogue_block<EPI, (EPI == DCV_EPI_PATCH ? 1 : 4), 4, 4, 0>(a, acc, cur.m0 + wm * 64, cur.n0 + wn * 64, r16, kg, bz, [&]() {
@@ -499,6 +595,12 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
                 if (nk > 1) nt_issue(nxt, 1, smem_base + ((g + 1) % NT_STAGES) * NT_STAGE_BYTES, dmaA, dmaW);
             }
         });
+#endif
+#if DCV_STAMP
+        st_t0 = clock64();
+        st_epi += st_t0 - st_t1;
+        ++st_n;
+#endif
         if (!has_next) break;
         if constexpr (HAS_BIAS) {
 #pragma unroll
@@ -508,132 +610,13 @@ __global__ __launch_bounds__(512) void gemm_nt_kernel(GemmNtArgs a) {
         cur = nxt;
         L = Ln;
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// gemm_nt_pair (round 4): the same product on a 128 x 128 tile by FOUR waves (2 x 2, each the 64 x 64 wave tile of gemm_nt_kernel), two
-// 32 KB stages = 64 KB of LDS, so that TWO workgroups share a CU.  Why: the ablation builds add up to the launch on all-zero operands too
-// (profiles/r04_x2_*) — k-loop and epilogue of a persistent one-workgroup-per-CU kernel run one after the other because every wave of the
-// CU is in the same phase; no schedule inside ONE instruction stream per SIMD overlaps them (in-order issue, one vmcnt queue per wave).
-// With two workgroups per CU each SIMD hosts a wave of either, and while one workgroup stores its tile (the epilogue runs at the HBM
-// write rate, ~14 B/clk per CU) the other's waves own the matrix pipe.  Price: 64 FLOP per operand byte instead of 85 / 154, and one stage
-// of prefetch — the k-loop itself is slower; the form pays where the epilogue is the larger part (two outputs, an auxiliary read).
-constexpr int NP_BM = 128, NP_BN = 128, NP_BK = 64;
-constexpr int NP_A_BYTES = NP_BM * NP_BK * 2, NP_W_BYTES = NP_BN * NP_BK * 2, NP_STAGE_BYTES = NP_A_BYTES + NP_W_BYTES;  // 32 KB
-constexpr int NP_SMEM = 2 * NP_STAGE_BYTES;                                                                              // 64 KB
-
-struct NpTile {
-    const bf16_t* gA[4];
-    const bf16_t* gW[4];
-    int m0, n0;
-};
-__device__ __forceinline__ void np_tile_setup(const GemmNtArgs& a, int L, int tiles_n, int wave, int lane, NpTile& t) {
-    const int tm = L / tiles_n, tn = L - tm * tiles_n;
-    t.m0 = tm * NP_BM;
-    t.n0 = tn * NP_BN;
-    // wave w fills A rows [32w, 32w+32) and W rows [32w, 32w+32): 4 + 4 pieces of 8 rows x 128 B per stage
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = 32 * wave + 8 * q + (lane >> 3);
-        t.gA[q] = a.A + (size_t)min(t.m0 + row, a.M - 1) * a.lda + (((lane & 7) ^ swz64n(row)) * 8);
-        t.gW[q] = a.W + (size_t)min(t.n0 + row, a.N - 1) * a.ldw + (((lane & 7) ^ swz64n(row)) * 8);
+#if DCV_STAMP  // stamps leave through aux2, or through out2 for the residual epilogue (whose aux2 is the DropPath factor)
+    void* const stamp_out = (EPI == DCV_EPI_BIAS_RESID_F32) ? a.out2 : (void*)a.aux2;
+    if (tid == 0 && stamp_out && EPI != DCV_EPI_PATCH) {
+        unsigned long long* sp = (unsigned long long*)stamp_out + 4 * blockIdx.x;
+        sp[0] = st_loop; sp[1] = st_epi; sp[2] = st_n; sp[3] = clock64();
     }
-}
-__device__ __forceinline__ void np_issue(const NpTile& t, int kt, unsigned stage_base, unsigned dmaA, unsigned dmaW) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(t.gA[q] + kt * NP_BK, stage_base + dmaA + q * 1024);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(t.gW[q] + kt * NP_BK, stage_base + dmaW + q * 1024);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_pair_kernel(GemmNtArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[NP_SMEM];
-    constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
-    static_assert(EPI != DCV_EPI_PATCH, "the tokeniser epilogue stays on the 256 x 128 kernel");
-    constexpr int S = nt_stores_per_wave<EPI>();
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (a.N + NP_BN - 1) / NP_BN;
-    const int tiles_m = (a.M + NP_BM - 1) / NP_BM;
-    const int total = tiles_m * tiles_n;
-    const int G = gridDim.x;
-    const int pos = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;  // an XCD gets a contiguous range of a round's tiles
-
-    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    const unsigned dmaA = 32 * wave * 128, dmaW = NP_A_BYTES + 32 * wave * 128;
-    const int nk = a.K / NP_BK;
-    const int r16 = lane & 15, kg = lane >> 4;
-    const int rowA = (wm * 64 + r16) * 128, rowW = NP_A_BYTES + (wn * 64 + r16) * 128;
-
-    int L = pos < total ? pos : -1;
-    int Lnext = (L >= 0 && L + G < total) ? L + G : -1;
-    if (L < 0) return;
-    NpTile cur, nxt;
-    np_tile_setup(a, L, tiles_n, wave, lane, cur);
-    int g = 0;  // global stage counter: stage g lives in buffer g & 1
-    np_issue(cur, 0, smem_base, dmaA, dmaW);
-    bool stores_behind = false;  // the previous tile's S epilogue stores were issued after this tile's first stage
-    float bz[8], bz_next[8];
-    if constexpr (HAS_BIAS) {
-        nt_load_bias<EPI, 4>(a, cur.n0 + wn * 64, r16, kg, bz);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(bz[e]));
-    }
-    for (;;) {
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-            // stage kt landed once only younger operations are outstanding: for kt == 0 the previous tile's S epilogue stores (issued behind
-            // this tile's first stage); afterwards nothing of ours is younger than the stage
-            if (kt == 0 && stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();  // stage g visible to all four waves; all are done reading buffer (g + 1) & 1
-            if (kt + 1 < nk) np_issue(cur, kt + 1, smem_base + ((g + 1) & 1) * NP_STAGE_BYTES, dmaA, dmaW);
-            const char* st = smem + (g & 1) * NP_STAGE_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[4], wf[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int co = ((4 * ks + kg) ^ swz64n(r16)) << 4;
-                    af[i] = as_bf16x8(lds_read128(st, rowA + i * 16 * 128 + co));
-                    wf[i] = as_bf16x8(lds_read128(st, rowW + i * 16 * 128 + co));
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);  // operands swapped: transposed tile (register epilogue)
-            }
-        }
-        // the next tile's first stage goes into buffer g & 1 = the buffer of stage g - 2, which every wave finished reading before the barrier
-        // of iteration g - 1: no barrier needed (the epilogue reads no LDS)
-        const int Ln = Lnext;
-        const bool has_next = Ln >= 0;
-        Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
-        const bool full = (cur.m0 + NP_BM <= a.M) && (cur.n0 + NP_BN <= a.N);
-        nt_epilogue_block<EPI, 4, 4, 4, 0>(a, acc, cur.m0 + wm * 64, cur.n0 + wn * 64, r16, kg, bz, [&]() {
-            if (has_next) {
-                np_tile_setup(a, Ln, tiles_n, wave, lane, nxt);
-                if constexpr (HAS_BIAS) nt_load_bias<EPI, 4>(a, nxt.n0 + wn * 64, r16, kg, bz_next);
-                np_issue(nxt, 0, smem_base + (g & 1) * NP_STAGE_BYTES, dmaA, dmaW);
-            }
-        });
-        if (!has_next) break;
-        if constexpr (HAS_BIAS) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bz[e] = bz_next[e];
-        }
-        stores_behind = full;
-        cur = nxt;
-        L = Ln;
-    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -644,6 +627,16 @@ __global__ __launch_bounds__(256) void gemm_nt_pair_kernel(GemmNtArgs a) {
 // (8 waves as 4 (M) x 2 (N), each 64 x 192 = 4 x 12 MFMA 16x16x32 tiles; the k-step's read / MFMA order is pinned, see the loop) and the
 // whole LDS: two 80 KB stages.  With two buffers the next stage is issued after the barrier that retires the previous
 // one, one k-iteration (48 MFMAs per wave) ahead.  Tile walk, register epilogue and fused ops as in gemm_nt_kernel.
+#if DCV_STAMP == 2
+// fine stamps (diagnostic build only): one statement = s_memtime + its wait, fenced for the scheduler (cdna guide, In-kernel stamps)
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#endif
 constexpr int N3_BM = 256, N3_BN = 384, N3_BK = 64;
 constexpr int N3_A_BYTES = N3_BM * N3_BK * 2, N3_W_BYTES = N3_BN * N3_BK * 2, N3_STAGE_BYTES = N3_A_BYTES + N3_W_BYTES;  // 80 KB
 constexpr int N3_SMEM = 2 * N3_STAGE_BYTES;                                                                              // 160 KB
@@ -661,6 +654,10 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     const bool late = (wave >> 2) != 0;  // waves w and w + 4 share a SIMD
     const int tiles_n = a.N / N3_BN;
     const int tiles_m = (a.M + N3_BM - 1) / N3_BM;
+#if DCV_STAGGER
+    if ((blockIdx.x >> 3) & 1)
+        for (int i = 0; i < DCV_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     const int total = tiles_m * tiles_n;
     const int G = gridDim.x;
     const int pos = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
@@ -692,7 +689,11 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     }
     auto issue = [&](int m0_, int n0_, int kt, unsigned stage_base) {
         const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);  // uniform by construction
+#if DCV_AWRAP
+        const bf16_t* ab = a.A + (size_t)(m0 % DCV_AWRAP) * a.lda + kt * N3_BK;
+#else
         const bf16_t* ab = a.A + (size_t)m0 * a.lda + kt * N3_BK;  // scalar
+#endif
         const bf16_t* wb = a.W + (size_t)n0 * a.ldw + kt * N3_BK;
         if (m0 + N3_BM <= a.M) {
 #pragma unroll
@@ -722,6 +723,12 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     issue(m0, n0, 0, smem_base);
     bool stores_behind = false;
 
+#if DCV_STAMP  // diagnostic build only (tools/gemm_stamp.py): per-workgroup cycles in the k-loop vs the epilogue, written through aux2
+    unsigned long long st_loop = 0, st_epi = 0, st_n = 0, st_t0 = clock64();
+#endif
+#if DCV_STAMP == 2
+    unsigned long long fs_vm = 0, fs_bar = 0, fs_issue = 0, fs_mfma = 0;
+#endif
     for (;;) {
         f32x4 acc[4][12];  // wave tile 64 x 192 = 4 x 12 MFMA tiles of 16 x 16
 #pragma unroll
@@ -735,11 +742,23 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         for (int kt = 0; kt < nk; ++kt, ++g) {
             // stage kt landed once only younger operations are outstanding: for kt == 0 the previous tile's S epilogue
             // stores (issued after this tile's first stage); afterwards nothing of ours is younger than the stage
+#if DCV_STAMP == 2
+            const unsigned long long f0 = stamp_now();
+#endif
             if (kt == 0 && stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(S) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if DCV_STAMP == 2
+            const unsigned long long f0b = stamp_now();
+#endif
             __builtin_amdgcn_s_barrier();  // stage g visible to all; all waves are done reading buffer (g+1)&1
+#if DCV_STAMP == 2
+            const unsigned long long f1 = stamp_now();
+#endif
             // (issuing half the waves' pieces between the two k-steps, as gemm_nt_kernel does, measured 3-5 % slower here: with two
             // stages the late pieces have half a stage to land)
+#if !DCV_READ_FIRST
+            if (kt + 1 < nk) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
+#endif
             const char* st = smem + (g & 1) * N3_STAGE_BYTES;
             // 24 steps (2 k-steps of 32 x 12 column blocks) of 4 MFMAs; the W fragment of step s + 2 is read at step s (ring of 3),
             // the 4 A fragments of the second k-step replace those of the first one by one behind their last MFMA.  The order
@@ -759,8 +778,13 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             wq[0] = rdW(0);
             wq[1] = rdW(1);
             __builtin_amdgcn_sched_barrier(0);
+#if DCV_READ_FIRST
             if (kt + 1 < nk && (DCV_N3_EARLY_AT < 0 || late)) issue(m0, n0, kt + 1, smem_base + ((g + 1) & 1) * N3_STAGE_BYTES);
             __builtin_amdgcn_sched_barrier(0);
+#endif
+#if DCV_STAMP == 2
+            const unsigned long long f2 = stamp_now();
+#endif
 #pragma unroll
             for (int s2 = 0; s2 < 24; ++s2) {
                 if (s2 + 2 < 24) wq[(s2 + 2) % 3] = rdW(s2 + 2);
@@ -775,9 +799,17 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if DCV_STAMP == 2
+            const unsigned long long f3 = stamp_now();
+            fs_vm += f0b - f0; fs_bar += f1 - f0b; fs_issue += f2 - f1; fs_mfma += f3 - f2;
+#endif
         }
         // The next tile's first stage goes into buffer g & 1 = the buffer of stage g-2, which every wave finished reading before the
         // barrier of iteration g-1: no barrier is needed here (the epilogue reads no LDS).
+#if DCV_STAMP
+        const unsigned long long st_t1 = clock64();
+        st_loop += st_t1 - st_t0;
+#endif
 
         // ---- epilogue straight from the accumulators, overlapped with the first stage of the next tile (into the other buffer) ----
         const int Ln = Lnext;
@@ -804,12 +836,31 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         });
         block(std::integral_constant<int, 4>{}, []() {});
         block(std::integral_constant<int, 8>{}, []() {});
+#if DCV_STAMP
+        st_t0 = clock64();
+        st_epi += st_t0 - st_t1;
+        ++st_n;
+#endif
         if (!has_next) break;
         stores_behind = full;
         m0 = m0n;
         n0 = n0n;
         L = Ln;
     }
+#if DCV_STAMP  // stamps leave through aux2, or through out2 for the residual epilogue (whose aux2 is the DropPath factor)
+    void* const stamp_out = (EPI == DCV_EPI_BIAS_RESID_F32) ? a.out2 : (void*)a.aux2;
+#endif
+#if DCV_STAMP == 1
+    if (tid == 0 && stamp_out) {
+        unsigned long long* sp = (unsigned long long*)stamp_out + 4 * blockIdx.x;
+        sp[0] = st_loop; sp[1] = st_epi; sp[2] = st_n; sp[3] = clock64();
+    }
+#elif DCV_STAMP == 2
+    if (lane == 0 && stamp_out) {  // per wave: vmcnt wait, barrier wait, reads + DMA issue, MFMA steps, epilogue, tiles
+        unsigned long long* sp = (unsigned long long*)stamp_out + 8 * (8 * blockIdx.x + wave);
+        sp[0] = fs_vm; sp[1] = fs_bar; sp[2] = fs_issue; sp[3] = fs_mfma; sp[4] = st_epi; sp[5] = st_n; sp[6] = st_loop; sp[7] = 0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -905,6 +956,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
         if (kt + 1 < nk) { TN_LOAD_TILE(kt + 1) }
         const char* sY = smem[cur][0];
         const char* sX = smem[cur][1];
+#if DCV_TABL != 2
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int row0 = 16 * ks + trow;
@@ -919,10 +971,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
+#else
+        asm volatile("" ::"v"(sY), "v"(sX));
+#endif
         if (kt + 1 < nk) { TN_STORE_TILE(cur ^ 1) }
         __syncthreads();
     }
 
+#if DCV_TABL == 1
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (a.M > 0) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1066,6 +1128,7 @@ __device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid) {
             }
             __syncthreads();
         }
+#if DCV_TABL != 2
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int row0 = 16 * ks + trow;
@@ -1079,7 +1142,13 @@ __device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
-        if (do_bias && (kt % tiles_q) == tq && brg < 10) {
+#else
+        asm volatile("" ::"v"(st));
+#endif
+#ifndef DCV_TN_BIAS_TQ0
+#define DCV_TN_BIAS_TQ0 0  // A/B switch: 1 = the round-2 assignment (the tq == 0 workgroups sum every stage)
+#endif
+        if (do_bias && (DCV_TN_BIAS_TQ0 ? tq == 0 : (kt % tiles_q) == tq) && brg < 10) {
             const int im = bch >> 4, ci = bch & 15;
             for (int r = brg; r < T3_BK; r += 10) {
                 const int pc = ((((ci >> 2) ^ (r & 3)) << 2) | (ci & 3));
@@ -1092,6 +1161,13 @@ __device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid) {
         }
     }
 #undef T3_ISSUE
+#if DCV_TABL == 1
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (a.M > 0) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1158,36 +1234,34 @@ static int dcv_cu_count() {
     return n;
 }
 
-#define DCV_NT_CASES(KERNEL, G) DCV_NT_CASES_T(KERNEL, G, 512)
-#define DCV_NT_CASES_T(KERNEL, G, THREADS)                                                             \
+#define DCV_NT_CASES(KERNEL, G)                                                                        \
     switch (epilogue) {                                                                                \
         case DCV_EPI_BIAS_BF16:                                                                        \
             if (!bias) return DCV_ERR_NULL;                                                            \
-            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_BF16>, dim3(G), dim3(THREADS), 0, s, a);                \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_BF16>, dim3(G), dim3(512), 0, s, a);                \
             break;                                                                                     \
         case DCV_EPI_BIAS_GELU_BF16:                                                                   \
             if (!bias || !out2) return DCV_ERR_NULL;                                                   \
-            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_GELU_BF16>, dim3(G), dim3(THREADS), 0, s, a);           \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_GELU_BF16>, dim3(G), dim3(512), 0, s, a);           \
             break;                                                                                     \
         case DCV_EPI_BIAS_RESID_F32:                                                                   \
             if (!bias) return DCV_ERR_NULL;                                                            \
-            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_RESID_F32>, dim3(G), dim3(THREADS), 0, s, a);           \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_BIAS_RESID_F32>, dim3(G), dim3(512), 0, s, a);           \
             break;                                                                                     \
         case DCV_EPI_PLAIN_BF16:                                                                       \
-            hipLaunchKernelGGL(KERNEL<DCV_EPI_PLAIN_BF16>, dim3(G), dim3(THREADS), 0, s, a);               \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_PLAIN_BF16>, dim3(G), dim3(512), 0, s, a);               \
             break;                                                                                     \
         case DCV_EPI_GELU_BWD_BF16:                                                                    \
             if (!aux) return DCV_ERR_NULL;                                                             \
-            hipLaunchKernelGGL(KERNEL<DCV_EPI_GELU_BWD_BF16>, dim3(G), dim3(THREADS), 0, s, a);            \
+            hipLaunchKernelGGL(KERNEL<DCV_EPI_GELU_BWD_BF16>, dim3(G), dim3(512), 0, s, a);            \
             break;
 
 // which kernel dcv_gemm_nt_ex launches for this problem (DCV_TILE_NARROW / DCV_TILE_WIDE), or a negative error for an illegal forced tile
 extern "C" int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile) {
-    if (tile < DCV_TILE_AUTO || tile > DCV_TILE_PAIR) return DCV_ERR_SHAPE;
+    if (tile < DCV_TILE_AUTO || tile > DCV_TILE_WIDE) return DCV_ERR_SHAPE;
     const bool legal384 = (N % N3_BN) == 0 && epilogue != DCV_EPI_PATCH;
     if (tile == DCV_TILE_WIDE) return legal384 ? DCV_TILE_WIDE : DCV_ERR_UNSUPPORTED;
     if (tile == DCV_TILE_NARROW) return DCV_TILE_NARROW;
-    if (tile == DCV_TILE_PAIR) return epilogue != DCV_EPI_PATCH ? DCV_TILE_PAIR : DCV_ERR_UNSUPPORTED;
     if (!legal384 || epilogue == DCV_EPI_GELU_BWD_BF16 || !(N >= 1152 || K >= 1536)) return DCV_TILE_NARROW;
     // Both kernels are persistent, so a launch costs rounds x time per tile, rounds = ceil(tiles / workgroups).  A 256 x 384 tile takes
     // 2.3 (K >= 1536: the k-loop dominates) to 2.5 (K = 384: the epilogue dominates) times a 256 x 128 tile (measured from the per-round
@@ -1215,7 +1289,7 @@ extern "C" int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, in
     if (!A || !W || !out) return DCV_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
-    if (grid_cap < 0 || tile < DCV_TILE_AUTO || tile > DCV_TILE_PAIR) return DCV_ERR_SHAPE;
+    if (grid_cap < 0 || tile < DCV_TILE_AUTO || tile > DCV_TILE_WIDE) return DCV_ERR_SHAPE;
     if (epilogue == DCV_EPI_BIAS_RESID_F32 && aux2 && (T <= 0 || (M % T) != 0)) return DCV_ERR_SHAPE;  // per-sample branch scale: T rows per sample
     // persistent kernels: one workgroup per CU walks the tiles; grid_cap (> 0) lowers the number of workgroups — the data-parallel
     // backward leaves CUs to RCCL's kernels this way (dichavit.py), tests force multi-round walks on small problems
@@ -1238,16 +1312,6 @@ extern "C" int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, in
         DCV_LAUNCH_CHECK();
         return DCV_OK;
     }
-    if (pick == DCV_TILE_PAIR) {
-        int gp = ((M + NP_BM - 1) / NP_BM) * ((N + NP_BN - 1) / NP_BN);
-        if (gp > 2 * cap) gp = 2 * cap;  // two workgroups per CU
-        DCV_NT_CASES_T(gemm_nt_pair_kernel, gp, 256)
-            default:
-                return DCV_ERR_UNSUPPORTED;
-        }
-        DCV_LAUNCH_CHECK();
-        return DCV_OK;
-    }
     int grid = ((M + NT_BM - 1) / NT_BM) * ((N + NT_BN - 1) / NT_BN);
     if (grid > cap) grid = cap;
     DCV_NT_CASES(gemm_nt_kernel, grid)
@@ -1262,7 +1326,6 @@ extern "C" int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, in
     return DCV_OK;
 }
 #undef DCV_NT_CASES
-#undef DCV_NT_CASES_T
 
 extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue,
                            const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,
