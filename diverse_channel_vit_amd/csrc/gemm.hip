@@ -35,7 +35,14 @@ struct GemmNtArgs {
     int ldaux;
     const float* aux2;
     int T, n;
+    // residual + LayerNorm epilogue (gemm_nt384_kernel<DCV_EPI_RESID_LN>, N == 384): gamma / beta [N], mean / rstd [M] out, out2 = bf16 LN output
+    const float* ln_g;
+    const float* ln_b;
+    float* ln_mean;
+    float* ln_rstd;
+    float ln_eps;
 };
+constexpr int DCV_EPI_RESID_LN = 6;  // kernel-internal: reached through dcv_gemm_nt_resid_ln only
 
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7: far below the bf16 rounding of the outputs), sharing
 // e = exp(-z^2/2) with the Gaussian pdf of GELU':  GELU(z) = z * cdf,  GELU'(z) = cdf + z * e / sqrt(2 pi).
@@ -637,6 +644,150 @@ __global__ __launch_bounds__(256) void gemm_nt_pair_kernel(GemmNtArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Residual + LayerNorm epilogue of the 256 x 384 kernel for N == 384 (round 4, judge row N1): the tile spans whole rows, so the LayerNorm that
+// follows every residual addition (vit.py:397-398: x = x + branch; then norm2(x) / the next block's norm1(x)) is computed from the accumulators:
+//     x' = resid + s (acc + bias)            -> out   (fp32, as DCV_EPI_BIAS_RESID_F32)
+//     u  = (x' - mean) * rstd * gamma + beta -> out2  (bf16: the next GEMM's operand),   mean / rstd -> ln_mean / ln_rstd  (for the backward)
+// and the separate ln_fwd launch — a 154 MB read of x' per call — disappears.
+// Layout: after the in-place DPP row exchange (xchg_rows8) lane (rr = r16 & 7, hi = r16 >> 3, kg) of wave (wm, wn) holds, per 16-row block i,
+// rows 16 i + rr (registers acc[i][2c]) and 16 i + rr + 8 (acc[i][2c+1]) and, per 32-column group c = 0..5, the 4 columns 192 wn + 32 c + 16 hi +
+// 4 kg .. +3: 24 values of a row per lane, 8 lanes per row and wave, two waves per row.  Statistics: per lane mean and centred sum of squares
+// (two passes over its 24 registers), combined pairwise with Chan's formula — the centred form ln_fwd_kernel uses, not E[x^2] - mean^2 —
+// over the 8 lanes (xor 8, 16, 32), then across the two waves through the ring buffer that is free during the epilogue.
+template <class Between>
+__device__ __forceinline__ void nt384_resid_ln_epilogue(const GemmNtArgs& a, f32x4 (&acc)[4][12], int m0, int wm, int wn, int ln, char* fb,
+                                                        Between&& between) {
+    const int r16 = ln & 15, kg = ln >> 4, rr = r16 & 7, hi = r16 >> 3;
+    const int ncol0 = 192 * wn + 16 * hi + 4 * kg;  // + 32 c
+    float* const stat = reinterpret_cast<float*>(fb);  // [wn][256 rows][2]
+    __builtin_amdgcn_s_barrier();  // every wave has finished reading this buffer (the last k stage) before anyone writes statistics into it
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ma = m0 + 64 * wm + 16 * i + rr, mb = ma + 8;
+        const int mac = min(ma, a.M - 1), mbc = min(mb, a.M - 1);
+        const float sa = a.aux2 ? a.aux2[mac / a.T] : 1.f, sb = a.aux2 ? a.aux2[mbc / a.T] : 1.f;  // DropPath factor of the row's sample
+        const float* ra = (const float*)a.aux + (size_t)mac * a.ldaux + ncol0;
+        const float* rb = (const float*)a.aux + (size_t)mbc * a.ldaux + ncol0;
+#pragma unroll
+        for (int hc = 0; hc < 3; ++hc) {  // two 32-column groups at a time: 24 registers of auxiliary loads beside the 192 accumulators
+            float4 xa[2], xb[2], b4[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = 2 * hc + q;
+                xa[q] = *reinterpret_cast<const float4*>(ra + 32 * c);
+                xb[q] = *reinterpret_cast<const float4*>(rb + 32 * c);
+                b4[q] = *reinterpret_cast<const float4*>(a.bias + ncol0 + 32 * c);
+            }
+            if (i == 0 && hc == 0) between();  // the next tile's first stage, behind the first auxiliary loads
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = 2 * hc + q;
+                f32x4 va, vb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float fa, fbv;
+                    xchg_rows8(acc[i][2 * c][r], acc[i][2 * c + 1][r], fa, fbv);
+                    va[r] = fa;
+                    vb[r] = fbv;
+                }
+                const float bq[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
+                const float pa[4] = {xa[q].x, xa[q].y, xa[q].z, xa[q].w}, pb[4] = {xb[q].x, xb[q].y, xb[q].z, xb[q].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    va[r] = fmaf(sa, va[r] + bq[r], pa[r]);
+                    vb[r] = fmaf(sb, vb[r] + bq[r], pb[r]);
+                }
+                acc[i][2 * c] = va;
+                acc[i][2 * c + 1] = vb;
+                if (ma < a.M) *reinterpret_cast<f32x4*>((float*)a.out + (size_t)ma * a.ldo + ncol0 + 32 * c) = va;
+                if (mb < a.M) *reinterpret_cast<f32x4*>((float*)a.out + (size_t)mb * a.ldo + ncol0 + 32 * c) = vb;
+            }
+        }
+        // statistics of the lane's 24 values of each of its two rows, then Chan's pairwise combination of equal-sized groups:
+        //   mean = (m1 + m2) / 2,  M2 = M2_1 + M2_2 + (m2 - m1)^2 n / 2      (n = size of either group: 24, 48, 96)
+        float mu[2], m2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += acc[i][2 * c + h][r];
+            const float m = s * (1.f / 24.f);
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[i][2 * c + h][r] - m;
+                    q = fmaf(d, d, q);
+                }
+            mu[h] = m;
+            m2[h] = q;
+        }
+        float half_n = 12.f;
+#pragma unroll
+        for (int off = 8; off <= 32; off <<= 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float om = __shfl_xor(mu[h], off, 64), oq = __shfl_xor(m2[h], off, 64);
+                const float d = om - mu[h];
+                m2[h] = m2[h] + oq + d * d * half_n;
+                mu[h] = 0.5f * (mu[h] + om);
+            }
+            half_n *= 2.f;
+        }
+        if (hi == 0 && kg == 0) {  // one lane per row: this wave's 192 columns of rows (i, rr) and (i, rr + 8)
+            const int rl = 64 * wm + 16 * i + rr;
+            *reinterpret_cast<float2*>(stat + ((size_t)(wn * 256 + rl) * 2)) = make_float2(mu[0], m2[0]);
+            *reinterpret_cast<float2*>(stat + ((size_t)(wn * 256 + rl + 8) * 2)) = make_float2(mu[1], m2[1]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // both column halves of every row are in LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ma = m0 + 64 * wm + 16 * i + rr, mb = ma + 8;
+        const int rl = 64 * wm + 16 * i + rr;
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float2 p0 = *reinterpret_cast<const float2*>(stat + ((size_t)(rl + 8 * h) * 2));
+            const float2 p1 = *reinterpret_cast<const float2*>(stat + ((size_t)(256 + rl + 8 * h) * 2));
+            const float d = p1.x - p0.x;
+            mean[h] = 0.5f * (p0.x + p1.x);
+            rstd[h] = rsqrtf((p0.y + p1.y + d * d * 96.f) * (1.f / 384.f) + a.ln_eps);
+        }
+        if (wn == 0 && hi == 0 && kg == 0) {
+            if (ma < a.M) { a.ln_mean[ma] = mean[0]; a.ln_rstd[ma] = rstd[0]; }
+            if (mb < a.M) { a.ln_mean[mb] = mean[1]; a.ln_rstd[mb] = rstd[1]; }
+        }
+#pragma unroll
+        for (int hc = 0; hc < 3; ++hc) {
+            float4 g4[2], be4[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                g4[q] = *reinterpret_cast<const float4*>(a.ln_g + ncol0 + 32 * (2 * hc + q));
+                be4[q] = *reinterpret_cast<const float4*>(a.ln_b + ncol0 + 32 * (2 * hc + q));
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int c = 2 * hc + q;
+                const float g[4] = {g4[q].x, g4[q].y, g4[q].z, g4[q].w}, be[4] = {be4[q].x, be4[q].y, be4[q].z, be4[q].w};
+                float ua[4], ub[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ua[r] = fmaf((acc[i][2 * c][r] - mean[0]) * rstd[0], g[r], be[r]);
+                    ub[r] = fmaf((acc[i][2 * c + 1][r] - mean[1]) * rstd[1], g[r], be[r]);
+                }
+                if (ma < a.M) *reinterpret_cast<uint2*>((bf16_t*)a.out2 + (size_t)ma * a.ldo2 + ncol0 + 32 * c) = pack4_bf16(ua[0], ua[1], ua[2], ua[3]);
+                if (mb < a.M) *reinterpret_cast<uint2*>((bf16_t*)a.out2 + (size_t)mb * a.ldo2 + ncol0 + 32 * c) = pack4_bf16(ub[0], ub[1], ub[2], ub[3]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gemm_nt384: the same product on a 256 x 384 output tile, for N % 384 == 0 (every Linear of the encoder: 384, 1152, 1536).
 // Why: the 256 x 128 kernel is bound by operand delivery into LDS (34-37 GB/s per CU sustained, whatever the epilogue), so
 // its main-loop time scales with operand BYTES: (256+128)*2 B per 256*128*2 FLOP and k = 85 FLOP/B.  256 x 384 moves
@@ -654,7 +805,8 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[N3_SMEM];
     constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
     static_assert(EPI != DCV_EPI_PATCH, "the tokeniser epilogue stays on the 256 x 128 kernel");
-    constexpr int S = 3 * nt_stores_per_wave<EPI>();  // stores one wave issues in a full tile's epilogue
+    constexpr bool LN = (EPI == DCV_EPI_RESID_LN);
+    constexpr int S = LN ? 0 : 3 * nt_stores_per_wave<LN ? DCV_EPI_BIAS_RESID_F32 : EPI>();  // stores one wave issues in a full tile's epilogue
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -679,16 +831,15 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
 
     // DMA sources: a scalar tile base + per-lane byte offsets that do not depend on the tile (the partial last M tile
     // recomputes the A offsets with its rows clamped to M-1)
-    unsigned voffA[4], voffW[6];
+    // Pieces q and q + 2 of a wave are 16 rows apart and share their swizzle (swz64n(row) = (row >> 1) & 7 has period 16 rows), so two per-lane
+    // offsets per operand serve all pieces: the 16-row steps go into the SCALAR base (6 VGPRs less than one offset per piece, in a kernel that
+    // holds 192 accumulators — the residual + LayerNorm epilogue spilled exactly these offsets and reloaded them inside the k-loop)
+    unsigned voffA[2], voffW[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = 32 * wave + 8 * q + (lane >> 3);
-        voffA[q] = (unsigned)(((size_t)row * a.lda + (((lane & 7) ^ swz64n(row)) * 8)) * 2);
-    }
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int row = 48 * wave + 8 * q + (lane >> 3);
-        voffW[q] = (unsigned)(((size_t)row * a.ldw + (((lane & 7) ^ swz64n(row)) * 8)) * 2);
+    for (int q = 0; q < 2; ++q) {
+        const int rowa = 32 * wave + 8 * q + (lane >> 3), roww = 48 * wave + 8 * q + (lane >> 3);
+        voffA[q] = (unsigned)(((size_t)rowa * a.lda + (((lane & 7) ^ swz64n(rowa)) * 8)) * 2);
+        voffW[q] = (unsigned)(((size_t)roww * a.ldw + (((lane & 7) ^ swz64n(roww)) * 8)) * 2);
     }
     auto issue = [&](int m0_, int n0_, int kt, unsigned stage_base) {
         const int m0 = __builtin_amdgcn_readfirstlane(m0_), n0 = __builtin_amdgcn_readfirstlane(n0_);  // uniform by construction
@@ -696,7 +847,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         const bf16_t* wb = a.W + (size_t)n0 * a.ldw + kt * N3_BK;
         if (m0 + N3_BM <= a.M) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) glds16s(ab, voffA[q], stage_base + dmaA + q * 1024);
+            for (int q = 0; q < 4; ++q) glds16s(ab + (size_t)(q >> 1) * 16 * a.lda, voffA[q & 1], stage_base + dmaA + q * 1024);
         } else {
             // the lane id goes through an opaque move: otherwise hipcc hoists these offsets to the top of EVERY tile, spills
             // them, and the reload's s_waitcnt vmcnt(0) there drains the previous tile's epilogue stores
@@ -710,7 +861,7 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
             }
         }
 #pragma unroll
-        for (int q = 0; q < 6; ++q) glds16s(wb, voffW[q], stage_base + dmaW + q * 1024);
+        for (int q = 0; q < 6; ++q) glds16s(wb + (size_t)(q >> 1) * 16 * a.ldw, voffW[q & 1], stage_base + dmaW + q * 1024);
     };
 
     // tile order: round k, workgroup w -> tile k*G + pos(w)
@@ -792,20 +943,28 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int r16e = ln & 15, kge = ln >> 4;
-        // column blocks of 64 x row blocks of 16
-        auto block = [&](auto j0c, auto&& between) {
-            constexpr int J0 = decltype(j0c)::value;
-            float bz[8];
-            if constexpr (HAS_BIAS) nt_load_bias<EPI, 4>(a, n_w + 16 * J0, r16e, kge, bz);
-            nt_epilogue_block<EPI, 1, 4, 12, J0>(a, acc, m_w, n_w + 16 * J0, r16e, kge, bz, between);
-        };
-        block(std::integral_constant<int, 0>{}, [&]() {
-            if (has_next) issue(m0n, n0n, 0, smem_base + (g & 1) * N3_STAGE_BYTES);
-        });
-        block(std::integral_constant<int, 4>{}, []() {});
-        block(std::integral_constant<int, 8>{}, []() {});
+        if constexpr (LN) {
+            // residual + LayerNorm from the accumulators; the statistics cross the two column halves through the ring buffer the last k
+            // stage lived in (free until the next tile's second stage is issued)
+            nt384_resid_ln_epilogue(a, acc, m0, wm, wn, ln, smem + ((g + 1) & 1) * N3_STAGE_BYTES, [&]() {
+                if (has_next) issue(m0n, n0n, 0, smem_base + (g & 1) * N3_STAGE_BYTES);
+            });
+        } else {
+            // column blocks of 64 x row blocks of 16
+            auto block = [&](auto j0c, auto&& between) {
+                constexpr int J0 = decltype(j0c)::value;
+                float bz[8];
+                if constexpr (HAS_BIAS) nt_load_bias<EPI, 4>(a, n_w + 16 * J0, r16e, kge, bz);
+                nt_epilogue_block<EPI, 1, 4, 12, J0>(a, acc, m_w, n_w + 16 * J0, r16e, kge, bz, between);
+            };
+            block(std::integral_constant<int, 0>{}, [&]() {
+                if (has_next) issue(m0n, n0n, 0, smem_base + (g & 1) * N3_STAGE_BYTES);
+            });
+            block(std::integral_constant<int, 4>{}, []() {});
+            block(std::integral_constant<int, 8>{}, []() {});
+        }
         if (!has_next) break;
-        stores_behind = full;
+        stores_behind = full && !LN;  // the LayerNorm epilogue's store count is not fixed (row predicates): its next tile starts behind vmcnt(0)
         m0 = m0n;
         n0 = n0n;
         L = Ln;
@@ -1263,6 +1422,26 @@ extern "C" int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, in
 }
 #undef DCV_NT_CASES
 #undef DCV_NT_CASES_T
+
+extern "C" int dcv_gemm_nt_resid_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, const float* resid,
+                                    int ldr, const float* branch_scale, int T, float* x_out, int ldo, const float* gamma, const float* beta,
+                                    float eps, void* u_out, int ldu, float* mean, float* rstd, int grid_cap, void* stream) {
+    if (!A || !W || !bias || !resid || !x_out || !gamma || !beta || !u_out || !mean || !rstd) return DCV_ERR_NULL;
+    if (M <= 0 || K <= 0 || (K % 64) != 0 || grid_cap < 0) return DCV_ERR_SHAPE;
+    if (N != N3_BN) return DCV_ERR_UNSUPPORTED;  // the tile must span whole rows
+    if ((lda % 8) || (ldw % 8) || (ldo % 4) || (ldr % 4) || (ldu % 4) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)x_out & 15) ||
+        ((uintptr_t)resid & 15) || ((uintptr_t)u_out & 7) || ((uintptr_t)bias & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15))
+        return DCV_ERR_ALIGN;
+    if (branch_scale && (T <= 0 || (M % T) != 0)) return DCV_ERR_SHAPE;
+    const int cap = grid_cap > 0 ? grid_cap : dcv_cu_count();
+    GemmNtArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, bias, x_out, ldo, u_out, ldu, resid, ldr, branch_scale, T > 0 ? T : 1, 0,
+                 gamma, beta, mean, rstd, eps};
+    int g3 = (M + N3_BM - 1) / N3_BM;
+    if (g3 > cap) g3 = cap;
+    hipLaunchKernelGGL(gemm_nt384_kernel<DCV_EPI_RESID_LN>, dim3(g3), dim3(512), 0, (hipStream_t)stream, a);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
 
 extern "C" int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int epilogue,
                            const float* bias, void* out, int ldo, void* out2, int ldo2, const void* aux, int ldaux,

@@ -366,6 +366,7 @@ class DiChaViT(nn.Module):
         # but measured SLOWER than the dQ + dK/dV pair at the headline shape in round 4 (1100-1500 us against 865 us per layer: the hand-off's
         # ~5 us edge latency against a 3.6-iteration budget per edge, profiles/r04_x1_*), so it is opt-in: DCV_ATTN_BWD_FUSED=1 / model.attn_bwd_fused = True
         self.attn_bwd_fused = os.environ.get("DCV_ATTN_BWD_FUSED", "0") == "1"
+        self.fuse_ln_fwd = os.environ.get("DCV_FUSE_LN", "1") != "0"  # forward LayerNorm inside the residual GEMMs' epilogue (dcv_gemm_nt_resid_ln; D = 384)
         self.wgrad_scratch_release = os.environ.get("DCV_WGRAD_RELEASE", "1") != "0"  # hand a layer's private scratch back once its last reader is queued
         self.wgrad_group = os.environ.get("DCV_WGRAD_GROUP", "1") != "0"  # a block's four weight gradients in one launch (needs the private scratch)
         self._group_cache = {}
@@ -753,13 +754,20 @@ class DiChaViT(nn.Module):
         xcur = xs.view(M, D)
         final_stride = N * D
         drop = self._drop_path_scales(B, dev)
+        # LayerNorm from the residual GEMM's accumulators (judge row N1, round 4): needs a tile that spans whole rows (D = 384, the 256 x 384 kernel)
+        fuse_ln = bool(self.fuse_ln_fwd) and D == 384
+        pre_ln = None
         for bi, blk in enumerate(fe.blocks):
             L = {}
             tail = self.cls_only_tail and bi == len(fe.blocks) - 1
             dsc = drop[bi] if drop is not None else None  # (attention branch, MLP branch) factors [B] or None
-            u1 = torch.empty(M, D, dtype=bf, device=dev)
-            mean1, rstd1 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
-            hip.ln_fwd(xcur, blk.norm1.weight, blk.norm1.bias, u1, mean1, rstd1, M, D, LN_EPS)
+            if pre_ln is not None:  # norm1 of this block came out of the previous block's fc2 + residual epilogue
+                u1, mean1, rstd1 = pre_ln
+                pre_ln = None
+            else:
+                u1 = torch.empty(M, D, dtype=bf, device=dev)
+                mean1, rstd1 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
+                hip.ln_fwd(xcur, blk.norm1.weight, blk.norm1.bias, u1, mean1, rstd1, M, D, LN_EPS)
             qkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
             hip.gemm_nt(u1, self._bf(blk.attn.qkv.weight), hip.EPI_BIAS_BF16, qkv, bias=blk.attn.qkv.bias)
             o = torch.empty(M, D, dtype=bf, device=dev)
@@ -780,18 +788,35 @@ class DiChaViT(nn.Module):
                 hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale)
                 o_c = None
                 xmid = torch.empty(M, D, dtype=f32, device=dev) if save else xcur
-                hip.gemm_nt(o, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=xcur,
-                            **(dict(aux2=dsc[0], T=N) if dsc else {}))
                 R = M
-            u2 = torch.empty(R, D, dtype=bf, device=dev)
-            mean2, rstd2 = torch.empty(R, dtype=f32, device=dev), torch.empty(R, dtype=f32, device=dev)
-            hip.ln_fwd(xmid, blk.norm2.weight, blk.norm2.bias, u2, mean2, rstd2, R, D, LN_EPS)
+                if fuse_ln:
+                    # attn.proj + residual AND norm2 from the accumulators of one launch (dcv_gemm_nt_resid_ln): no re-read of xmid
+                    u2 = torch.empty(R, D, dtype=bf, device=dev)
+                    mean2, rstd2 = torch.empty(R, dtype=f32, device=dev), torch.empty(R, dtype=f32, device=dev)
+                    hip.gemm_nt_resid_ln(o, self._bf(blk.attn.proj.weight), blk.attn.proj.bias, xcur, xmid, blk.norm2.weight, blk.norm2.bias,
+                                         LN_EPS, u2, mean2, rstd2, **(dict(branch_scale=dsc[0], T=N) if dsc else {}))
+                else:
+                    hip.gemm_nt(o, self._bf(blk.attn.proj.weight), hip.EPI_BIAS_RESID_F32, xmid, bias=blk.attn.proj.bias, aux=xcur,
+                                **(dict(aux2=dsc[0], T=N) if dsc else {}))
+            if tail or not fuse_ln:
+                u2 = torch.empty(R, D, dtype=bf, device=dev)
+                mean2, rstd2 = torch.empty(R, dtype=f32, device=dev), torch.empty(R, dtype=f32, device=dev)
+                hip.ln_fwd(xmid, blk.norm2.weight, blk.norm2.bias, u2, mean2, rstd2, R, D, LN_EPS)
             z = torch.empty(R, 4 * D, dtype=bf, device=dev)  # GELU'(pre-activation), saved for the backward
             hact = torch.empty(R, 4 * D, dtype=bf, device=dev)
             hip.gemm_nt(u2, self._bf(blk.mlp.fc1.weight), hip.EPI_BIAS_GELU_BF16, z, bias=blk.mlp.fc1.bias, out2=hact)
             xout = torch.empty(R, D, dtype=f32, device=dev) if (save or tail) else xmid
-            hip.gemm_nt(hact, self._bf(blk.mlp.fc2.weight), hip.EPI_BIAS_RESID_F32, xout, bias=blk.mlp.fc2.bias, aux=xmid,
-                        **(dict(aux2=dsc[1], T=R // B) if dsc else {}))
+            nxt = fe.blocks[bi + 1] if bi + 1 < len(fe.blocks) else None
+            if fuse_ln and not tail and nxt is not None:
+                # mlp.fc2 + residual AND the NEXT block's norm1 (its full rows are needed even when that block is the CLS-only tail: keys and values)
+                un = torch.empty(M, D, dtype=bf, device=dev)
+                mn, rn = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
+                hip.gemm_nt_resid_ln(hact, self._bf(blk.mlp.fc2.weight), blk.mlp.fc2.bias, xmid, xout, nxt.norm1.weight, nxt.norm1.bias, LN_EPS,
+                                     un, mn, rn, **(dict(branch_scale=dsc[1], T=R // B) if dsc else {}))
+                pre_ln = (un, mn, rn)
+            else:
+                hip.gemm_nt(hact, self._bf(blk.mlp.fc2.weight), hip.EPI_BIAS_RESID_F32, xout, bias=blk.mlp.fc2.bias, aux=xmid,
+                            **(dict(aux2=dsc[1], T=R // B) if dsc else {}))
             if save:
                 L.update(drop=dsc)
                 L.update(x_in=xcur, u1=u1, mean1=mean1, rstd1=rstd1, qkv=qkv, o=o, lse=lse, x_mid=xmid, u2=u2, mean2=mean2,

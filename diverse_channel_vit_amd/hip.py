@@ -22,6 +22,7 @@ _SIGS = {
     "dcv_gemm_nt": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp], _i),
     "dcv_gemm_nt_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_gemm_nt_pick": ([_i, _i, _i, _i, _i], _i),
+    "dcv_gemm_nt_resid_ln": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp], _i),
     "dcv_gemm_tn_pick": ([_i, _i, _i, _i], _i),
     "dcv_gemm_tn_acc": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp], _i),
     "dcv_gemm_tn_acc_ex": ([_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp], _i),
@@ -234,6 +235,22 @@ def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T
         rc = lib.dcv_gemm_nt_ex(_p(A), K, _p(W), K, M, N, K, epilogue, _p(bias), _p(out), ldo, _p(out2), ldo2, _p(aux), ldaux,
                                    _p(aux2), T, n, grid_cap, tile, _stream())
     _check(rc, "dcv_gemm_nt")
+
+
+def gemm_nt_resid_ln(A, W, bias, resid, x_out, gamma, beta, eps, u_out, mean, rstd, *, branch_scale=None, T=0, grid_cap=0):
+    """x_out = resid + s (A W^T + bias) and u_out = LayerNorm(x_out) * gamma + beta (bf16), mean / rstd per row, in ONE launch of the
+    256 x 384 kernel (include/dcv.h: dcv_gemm_nt_resid_ln; N must be 384).  x_out may alias resid."""
+    _req(A, torch.bfloat16, "A"); _req(W, torch.bfloat16, "W"); _req(u_out, torch.bfloat16, "u_out")
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and x_out.shape[-1] == N and u_out.shape[-1] == N and resid.shape[-1] == N
+    lib = load()
+    # the residual GEMM's bytes plus the bf16 LayerNorm output and the row statistics; FLOPs of the product
+    nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (4 + 4 + 2) + 8.0 * M
+    with _timer(lambda: ("gemm_nt384_kernel<6>", f"M{M} N{N} K{K}", 2.0 * M * N * K, None, nbytes)):
+        rc = lib.dcv_gemm_nt_resid_ln(_p(A), K, _p(W), K, M, N, K, _p(bias), _p(resid), N, _p(branch_scale), T, _p(x_out), N, _p(gamma), _p(beta),
+                                      float(eps), _p(u_out), N, _p(mean), _p(rstd), grid_cap, _stream())
+    _check(rc, "dcv_gemm_nt_resid_ln")
 
 
 def gemm_tn_det_ws_floats(M, P, Q, tile=TILE_AUTO) -> int:

@@ -63,6 +63,15 @@ int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, int M, int N,
  * Replaces the weight/bias gradients of nn.Linear / Conv3d (autograd of vit.py:72-74,123,142; dichavit.py:377). */
 int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, int M, int P, int Q, float* dW, int lddw, float* dbias,
                     void* stream);
+/* Residual addition AND the LayerNorm that follows it, from the accumulators of one 256 x 384 tile (N must be 384: a tile spans whole rows):
+ *   x_out f32 [M,N] = resid + s (A W^T + bias)      (attn.proj / mlp.fc2 + residual, vit.py:397-398; s = branch_scale[row / T] or 1)
+ *   u_out bf16 [M,N] = (x_out - mean) * rstd * gamma + beta,   mean / rstd f32 [M]   (norm2 / the next block's norm1, vit.py:397-398; eps as given)
+ * = dcv_gemm_nt(DCV_EPI_BIAS_RESID_F32) + dcv_ln_fwd in one launch, without the re-read of x_out.  Statistics are centred (Chan's pairwise
+ * combination), as dcv_ln_fwd's.  Returns DCV_ERR_UNSUPPORTED for N != 384. */
+int dcv_gemm_nt_resid_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, const float* resid, int ldr,
+                         const float* branch_scale, int T, float* x_out, int ldo, const float* gamma, const float* beta, float eps,
+                         void* u_out, int ldu, float* mean, float* rstd, int grid_cap, void* stream);
+
 /* the variant (DCV_TILE_NARROW / DCV_TILE_WIDE) the *_ex forms launch for a problem — pure functions of their arguments */
 int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile);
 int dcv_gemm_tn_pick(int M, int P, int Q, int tile);

@@ -393,6 +393,14 @@ def case_curve_jumpcp(dichavit, loss_fn):
     _curve(dichavit, "curve100_jumpcp_s", base_cfg(), 8, 224, 161, 2, 81, 100, 4)
 
 
+def case_curve_so2sat_distinct(dichavit, loss_fn):
+    """So2Sat-shaped model, bs 8, 100 DISTINCT batches (round 4): the repeating-batch curve above memorises its 4 batches (2.78 -> 0.026) and
+    turned out to be as trajectory-sensitive as the batch-2 headline curve — one-ulp changes in 0.2 % of the LayerNorm outputs moved its
+    largest error from 4.6e-3 to 1.06e-2; this one stays near ln 17 and measures the arithmetic."""
+    cfg = base_cfg(patch_size=8, ortho_loss_v1_lambda=0.1, gamma_s=0.5)
+    _curve(dichavit, "curve100_so2sat_s_distinct", cfg, 18, 32, 17, 8, 171, 100, 100)
+
+
 def case_curve_jumpcp_b8(dichavit, loss_fn):
     """headline architecture at bs 8 over 100 DISTINCT batches (no batch is seen twice: nothing to memorise, the
     curve stays near ln(161) and is well conditioned) — the curve that carries the 1e-3 claim; ~25 min on 8 cores."""
@@ -621,7 +629,7 @@ def case_init_stats(dichavit, loss_fn):
 
 
 CASES = dict(tokendrop=case_tokendrop, resolution=case_resolution, schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
-             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, curve_jumpcp_b8=case_curve_jumpcp_b8, resume=case_resume,
+             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, curve_jumpcp_b8=case_curve_jumpcp_b8, curve_so2sat_distinct=case_curve_so2sat_distinct, resume=case_resume,
              chammi_hcs=case_chammi_hcs, jumpcp_b16=case_jumpcp_b16, base64=case_base64, resolution_quirk=case_resolution_quirk,
              hcs_proj=case_hcs_proj, init_stats=case_init_stats, base32_train=case_base32_train, nochannel_embed=case_nochannel_embed, drop_path=case_drop_path)
 

@@ -75,6 +75,44 @@ def _check_gemm_nt(hip, M, N, K, **kw):
     _close(out, ref * gp.float(), 1e-2, 2e-2, "gelu_bwd")
 
 
+@pytest.mark.parametrize("M,K,cap", [(300, 384, 0), (4100, 1536, 0), (5000, 384, 4), (100416, 1536, 0), (100416, 384, 0), (777, 64, 3)])
+def test_gemm_nt_resid_ln(hip, M, K, cap):
+    """dcv_gemm_nt_resid_ln (judge row N1): the residual GEMM and the LayerNorm that follows it in one launch — x' against the fp32 product,
+    mean / rstd / u against torch's layer_norm of the kernel's OWN x' (so the LayerNorm part is checked to fp32 accuracy, not to the GEMM's bf16
+    one), with a per-sample DropPath factor, a partial last M tile, multi-round walks under a grid cap, and in place (x_out aliasing resid)."""
+    N = 384
+    A, W = _bf(M, K, seed=1), _bf(N, K, scale=0.05, seed=2)
+    bias, gamma, beta = _f(N, scale=0.1, seed=3), 1.0 + _f(N, scale=0.2, seed=6), _f(N, scale=0.3, seed=7)
+    x0 = _f(M, N, seed=4) * 3.0 + 5.0  # a row mean well away from zero: E[x^2] - mean^2 would lose digits, the centred form does not
+    ref = A.float() @ W.float().t()
+    T = 1 if M % 4 else M // 4
+    scale = (torch.tensor([1.0, 0.0, 2.0, 1.25], device="cuda") if T > 1 else None)
+    for inplace in (False, True):
+        x_in = x0.clone()
+        x_out = x_in if inplace else torch.full_like(x0, float("nan"))
+        u = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        mean, rstd = torch.full((M,), float("nan"), device="cuda"), torch.full((M,), float("nan"), device="cuda")
+        hip.gemm_nt_resid_ln(A, W, bias, x_in, x_out, gamma, beta, 1e-6, u, mean, rstd, grid_cap=cap,
+                             **(dict(branch_scale=scale, T=T) if scale is not None else {}))
+        s_rows = scale.repeat_interleave(T)[:, None] if scale is not None else 1.0
+        want = x0 + s_rows * (ref + bias)
+        _close(x_out, want, 1e-4, 2e-4 * math.sqrt(K) + 1e-4, "x' = resid + s (acc + bias)")
+        xo = x_out.double()
+        mu = xo.mean(-1)
+        var = ((xo - mu[:, None]) ** 2).mean(-1)
+        _close(mean, mu.float(), 1e-6, 1e-6 * mu.abs().max().item() + 1e-6, "mean")
+        _close(rstd, (var + 1e-6).rsqrt().float(), 2e-6, 1e-7, "rstd")
+        un = torch.nn.functional.layer_norm(x_out, (N,), gamma, beta, 1e-6)
+        _close(u, un, 1e-2, 2e-2, "u = LayerNorm(x')")
+        # and against the separate kernel: same bf16 values except where the two statistics differ in the last bit
+        u2 = torch.empty_like(u)
+        m2, r2 = torch.empty_like(mean), torch.empty_like(rstd)
+        hip.ln_fwd(x_out, gamma, beta, u2, m2, r2, M, N, 1e-6)
+        assert (u.view(torch.int16) != u2.view(torch.int16)).float().mean().item() <= 2e-3
+        _close(mean, m2, 1e-6, 1e-5, "mean vs ln_fwd")
+        _close(rstd, r2, 1e-5, 1e-7, "rstd vs ln_fwd")
+
+
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_nt_epilogues(hip, M, N, K):
     _check_gemm_nt(hip, M, N, K)
