@@ -376,24 +376,10 @@ def main():
         order = [True, False]
     else:
         order = [bool(args.overlap) if dp is not None and (args.overlap or args.no_overlap) else (dp.overlap if dp is not None else None)]
-    best = None
-    for mi, mode in enumerate(order):
-        if dp is not None:
-            dp.overlap = bool(mode)
-            if mi > 0:
-                for _ in range(2):  # untimed: the first steps in a mode allocate its buffers
-                    step()
-        r = timed_region()
-        if dp is not None:
-            dp_modes["overlap" if mode else "single_allreduce_after_backward"] = {
-                "images_per_sec": round(args.batch * world * args.steps / r[0], 2), "ms_per_step": round(r[0] / args.steps * 1e3, 3),
-                "median_ms_per_step": round(r[1], 3)}
-        if best is None or r[0] < best[1][0]:
-            best = (mode, r)
-    chosen_mode, (dt, med_ms, live, loss) = best
-    final_loss = loss.item()
-
-    if rank == 0:
+    def build_line(dt, med_ms, live, final_loss, chosen_mode):
+        """The JSON line from one timed region (rank 0 only; None elsewhere)."""
+        if rank != 0:
+            return None
         B, C, H = args.batch, args.channels, {"tiny": 3, "small": 6, "base": 12, "distill": 6}[args.arch]
         headline = (args.arch, C, args.img, args.batch, args.classes) == ("small", 8, 224, 64, 161) and not args.hcs and not args.chammi
         n = (args.img // 16) ** 2
@@ -536,6 +522,51 @@ def main():
                           "reserved_cus": dp.reserved_cus}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.channels, args.img, args.classes)
+        return line
+
+    # N > 1: the single all-reduce after the backward is timed FIRST (the simple mode: nothing runs beside the backward), the overlapped
+    # per-layer buckets second, under a watchdog: that mode has never met real asynchronous collectives on two devices (no such box in four
+    # rounds) — if it does not finish, every rank prints / exits with the first mode's line instead of hanging the scaling run.
+    if len(order) == 2:
+        order = [False, True]
+    best = None
+    fallback = None
+    for mi, mode in enumerate(order):
+        if dp is not None:
+            dp.overlap = bool(mode)
+        watchdog = None
+        wd_env = os.environ.get("DCV_BENCH_WATCHDOG_S")  # test hook: arms the watchdog at any world size with this limit
+        if dp is not None and mi > 0 and (world > 1 or wd_env):
+            import threading
+            limit = float(wd_env) if wd_env else max(180.0, 30.0 * best[1][0])
+
+            def bail(limit=limit):
+                if rank == 0 and fallback is not None:
+                    fallback["dp"]["modes"]["overlap"] = {"status": f"did not finish within {limit:.0f} s: the line reports the single all-reduce mode"}
+                    fallback["dp"]["rccl_channels_in_use"] = dcv.DataParallel.rccl_channels_from_log(rccl_log) if rccl_log else None
+                    print(json.dumps(fallback), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(limit, bail)
+            watchdog.daemon = True
+            watchdog.start()
+        if dp is not None and mi > 0:
+            for _ in range(2):  # untimed: the first steps in a mode allocate its buffers
+                step()
+        r = timed_region()
+        if watchdog is not None:
+            watchdog.cancel()
+        if dp is not None:
+            dp_modes["overlap" if mode else "single_allreduce_after_backward"] = {
+                "images_per_sec": round(args.batch * world * args.steps / r[0], 2), "ms_per_step": round(r[0] / args.steps * 1e3, 3),
+                "median_ms_per_step": round(r[1], 3)}
+        if best is None or r[0] < best[1][0]:
+            best = (mode, r)
+        if dp is not None and mi == 0 and len(order) > 1 and (world > 1 or wd_env):
+            fallback = build_line(r[0], r[1], r[2], r[3].item(), mode)
+    chosen_mode, (dt, med_ms, live, loss) = best
+    final_loss = loss.item()
+    line = build_line(dt, med_ms, live, final_loss, chosen_mode)
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()
