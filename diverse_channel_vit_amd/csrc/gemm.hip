@@ -743,8 +743,16 @@ __device__ __forceinline__ void nt384_resid_ln_epilogue(const GemmNtArgs& a, f32
             *reinterpret_cast<float2*>(stat + ((size_t)(wn * 256 + rl + 8) * 2)) = make_float2(mu[1], m2[1]);
         }
     }
+    {  // gamma and beta into the same buffer (3 KB): phase 2 reads them back per column group with 16-byte LDS reads instead of holding
+       // 48 registers or waiting for six dependent global loads per row block
+        const int t = 64 * (2 * wm + wn) + ln;
+        if (t < 192) {
+            const float4 v = *reinterpret_cast<const float4*>((t < 96 ? a.ln_g : a.ln_b) + 4 * (t < 96 ? t : t - 96));
+            *reinterpret_cast<float4*>(stat + 1024 + 4 * t) = v;  // gamma at float 1024, beta at 1024 + 384
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // both column halves of every row are in LDS
+    __builtin_amdgcn_s_barrier();  // both column halves of every row (and gamma / beta) are in LDS
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ma = m0 + 64 * wm + 16 * i + rr, mb = ma + 8;
@@ -767,9 +775,14 @@ __device__ __forceinline__ void nt384_resid_ln_epilogue(const GemmNtArgs& a, f32
             float4 g4[2], be4[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                g4[q] = *reinterpret_cast<const float4*>(a.ln_g + ncol0 + 32 * (2 * hc + q));
-                be4[q] = *reinterpret_cast<const float4*>(a.ln_b + ncol0 + 32 * (2 * hc + q));
+                g4[q] = *reinterpret_cast<const float4*>(stat + 1024 + ncol0 + 32 * (2 * hc + q));
+                be4[q] = *reinterpret_cast<const float4*>(stat + 1024 + 384 + ncol0 + 32 * (2 * hc + q));
             }
+            // bf16 u of the column groups c = 2 hc and c + 1, then a 16-lane-row swap (v_permlane16_swap) between the lanes kg and kg ^ 1, which hold
+            // adjacent 4-column pieces of both groups: afterwards an even-kg lane holds 8 consecutive columns of group c, its odd partner 8
+            // consecutive columns of group c + 1 — the 8 lanes of a row cover 128 contiguous bytes, whole cache lines per store instruction
+            // (with 8 bytes per lane the same stores touched 64-byte segments: fc2 + residual + LN 211 -> 201 us, proj 124 -> 112.5 us)
+            uint2 pa[2], pb[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int c = 2 * hc + q;
@@ -780,9 +793,17 @@ __device__ __forceinline__ void nt384_resid_ln_epilogue(const GemmNtArgs& a, f32
                     ua[r] = fmaf((acc[i][2 * c][r] - mean[0]) * rstd[0], g[r], be[r]);
                     ub[r] = fmaf((acc[i][2 * c + 1][r] - mean[1]) * rstd[1], g[r], be[r]);
                 }
-                if (ma < a.M) *reinterpret_cast<uint2*>((bf16_t*)a.out2 + (size_t)ma * a.ldo2 + ncol0 + 32 * c) = pack4_bf16(ua[0], ua[1], ua[2], ua[3]);
-                if (mb < a.M) *reinterpret_cast<uint2*>((bf16_t*)a.out2 + (size_t)mb * a.ldo2 + ncol0 + 32 * c) = pack4_bf16(ub[0], ub[1], ub[2], ub[3]);
+                pa[q] = pack4_bf16(ua[0], ua[1], ua[2], ua[3]);
+                pb[q] = pack4_bf16(ub[0], ub[1], ub[2], ub[3]);
             }
+            const u32x2_t ax = __builtin_amdgcn_permlane16_swap(pa[0].x, pa[1].x, false, false);
+            const u32x2_t ay = __builtin_amdgcn_permlane16_swap(pa[0].y, pa[1].y, false, false);
+            const u32x2_t bx = __builtin_amdgcn_permlane16_swap(pb[0].x, pb[1].x, false, false);
+            const u32x2_t by = __builtin_amdgcn_permlane16_swap(pb[0].y, pb[1].y, false, false);
+            const int kgp = kg & 1;
+            const int ucol = 192 * wn + 32 * (2 * hc + kgp) + 16 * hi + 4 * (kg - kgp);
+            if (ma < a.M) *reinterpret_cast<uint4*>((bf16_t*)a.out2 + (size_t)ma * a.ldo2 + ucol) = make_uint4(ax[0], ay[0], ax[1], ay[1]);
+            if (mb < a.M) *reinterpret_cast<uint4*>((bf16_t*)a.out2 + (size_t)mb * a.ldo2 + ucol) = make_uint4(bx[0], by[0], bx[1], by[1]);
         }
     }
 }
