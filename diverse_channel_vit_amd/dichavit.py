@@ -755,7 +755,10 @@ class DiChaViT(nn.Module):
         final_stride = N * D
         drop = self._drop_path_scales(B, dev)
         # LayerNorm from the residual GEMM's accumulators (judge row N1, round 4): needs a tile that spans whole rows (D = 384, the 256 x 384 kernel)
-        fuse_ln = bool(self.fuse_ln_fwd) and D == 384
+        # ... and enough rows to fill the chip with 256-row tiles: below ~96 tiles (M < 24.5 k rows: the CHAMMI sub-batches, 12-22 k rows) the residual GEMM
+        # on the narrow kernel's three-times-as-many tiles plus a separate ln_fwd is faster (measured: CHAMMI step 29.5 vs 30.6 ms, bs 16 equal, bs 32
+        # 19.1 -> 18.6 ms, bs 64 36.45 -> 35.85 ms)
+        fuse_ln = bool(self.fuse_ln_fwd) and D == 384 and (M + 255) // 256 >= 96
         pre_ln = None
         for bi, blk in enumerate(fe.blocks):
             L = {}
