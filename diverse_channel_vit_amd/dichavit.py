@@ -366,6 +366,7 @@ class DiChaViT(nn.Module):
         # but measured SLOWER than the dQ + dK/dV pair at the headline shape in round 4 (1100-1500 us against 865 us per layer: the hand-off's
         # ~5 us edge latency against a 3.6-iteration budget per edge, profiles/r04_x1_*), so it is opt-in: DCV_ATTN_BWD_FUSED=1 / model.attn_bwd_fused = True
         self.attn_bwd_fused = os.environ.get("DCV_ATTN_BWD_FUSED", "0") == "1"
+        self.fuse_ln_min_tiles = int(os.environ.get("DCV_FUSE_LN_MIN_TILES", "96"))  # 256-row tiles below which the fusion does not pay (_run_forward)
         self.fuse_ln_fwd = os.environ.get("DCV_FUSE_LN", "1") != "0"  # forward LayerNorm inside the residual GEMMs' epilogue (dcv_gemm_nt_resid_ln; D = 384)
         self.wgrad_scratch_release = os.environ.get("DCV_WGRAD_RELEASE", "1") != "0"  # hand a layer's private scratch back once its last reader is queued
         self.wgrad_group = os.environ.get("DCV_WGRAD_GROUP", "1") != "0"  # a block's four weight gradients in one launch (needs the private scratch)
@@ -758,7 +759,7 @@ class DiChaViT(nn.Module):
         # ... and enough rows to fill the chip with 256-row tiles: below ~96 tiles (M < 24.5 k rows: the CHAMMI sub-batches, 12-22 k rows) the residual GEMM
         # on the narrow kernel's three-times-as-many tiles plus a separate ln_fwd is faster (measured: CHAMMI step 29.5 vs 30.6 ms, bs 16 equal, bs 32
         # 19.1 -> 18.6 ms, bs 64 36.45 -> 35.85 ms)
-        fuse_ln = bool(self.fuse_ln_fwd) and D == 384 and (M + 255) // 256 >= 96
+        fuse_ln = bool(self.fuse_ln_fwd) and D == 384 and (M + 255) // 256 >= self.fuse_ln_min_tiles
         pre_ln = None
         for bi, blk in enumerate(fe.blocks):
             L = {}

@@ -473,7 +473,7 @@ def test_loss_curve_100_steps(gpu_device):
     of the So2Sat-shaped model at bs 8 over 4 REPEATING batches (tests/golden/curve100_so2sat_s.npz; the loss falls 2.78 -> 0.026: the run
     memorises its batches).  SMOKE BOUND ONLY since round 4.
 
-    Finding (round 4).  Rounds 2-3 treated this curve as well conditioned and asserted it at 1.2 x one build's value (step 0 1.06e-3, max
+    Finding (round 4; reproduce with DCV_FUSE_LN_MIN_TILES=0 — at this model's 2 312 token rows the fusion is off by default).  Rounds 2-3 treated this curve as well conditioned and asserted it at 1.2 x one build's value (step 0 1.06e-3, max
     4.575e-3, mean 4.759e-4, last 20 steps 1.108e-4).  Moving the forward LayerNorm into the residual GEMM's epilogue — the same arithmetic:
     mean / rstd equal to 1e-6, 0.2 % of the bf16 outputs different by one ulp (test_gemm_nt_resid_ln) — moved it to step 0 6.06e-4, max 1.056e-2,
     mean 7.582e-4, last 20 6.097e-5: better at both ends, 2.3x worse at its worst early step.  A curve that a one-ulp perturbation moves by that
