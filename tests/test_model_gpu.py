@@ -76,10 +76,16 @@ def check_grads(model, sd_ref, rel_tol=5e-2, cos_tol=0.998):
     return worst
 
 
-@pytest.mark.parametrize("name", ["tiny_e2e", "so2sat_s", "jumpcp_s"])
+@pytest.mark.parametrize("name", ["tiny_e2e", "so2sat_s", "jumpcp_s", "so2sat_s/fused_ln", "jumpcp_s/fused_ln"])
 def test_train_step_parity(gpu_device, name):
+    """One train step against the real reference's golden and, gradient by gradient, against the fp64 oracle.  The `/fused_ln` variants force the
+    forward LayerNorm into the residual GEMMs' epilogue (dcv_gemm_nt_resid_ln) at these small row counts, where it is off by default
+    (model.fuse_ln_min_tiles): same goldens, same tolerances; `jumpcp_s_b16` and the bench-grid tests run it at its default size."""
+    name, _, variant = name.partition("/")
     meta, a = load_golden(name)
     model, _ = build(meta, gpu_device)
+    if variant == "fused_ln":
+        model.fuse_ln_min_tiles = 0
     x, y = orc.make_batch(meta["seed"] + 1, meta["B"], meta["C_in"], meta["img"], meta["num_classes"])
     out, extra = model(x.to(gpu_device), meta["chunk"], None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
     assert extra.shape == torch.Size([])
