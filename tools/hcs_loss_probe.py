@@ -1,3 +1,6 @@
+"""|loss - golden| of the six recorded HCS draws (tests/golden/hcs.npz) with the forward LayerNorm fused or not, stochastic or round-to-nearest
+weight copies (round 4: the single-channel draw sits at 4.9e-3 / 5.1e-3 with stochastic copies, 1e-4 .. 2e-3 with round-to-nearest — the spread is
+the weight-rounding noise of ONE forward, not the kernels).  python tools/hcs_loss_probe.py   (GPU)"""
 import os, sys, random
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, torch
@@ -9,7 +12,7 @@ meta, a = load_golden("hcs")
 for fuse in (0, 1):
     for sr in (True, False):
         model, _ = T.build(meta, dev)
-        model.fuse_ln_fwd = bool(fuse)
+        model.fuse_ln_fwd = bool(fuse); model.fuse_ln_min_tiles = 0
         model.stochastic_weight_rounding = sr
         x, y = orc.make_batch(42, 3, 6, 32, 7)
         errs = []
