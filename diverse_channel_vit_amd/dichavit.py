@@ -1124,6 +1124,15 @@ class DiChaViT(nn.Module):
     # ---------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, chunk_name: str, training_chunks: Optional[str] = None, init_first_layer=None,
                 new_channel_init=None, **kwargs):
+        """models/dichavit.py:844-861.  The reference's trainer wraps this call in `torch.cuda.amp.autocast(enabled=use_amp)` (trainer.py:861,
+        default off).  The path chooses its own operand precision (bf16 MFMA operands, fp32 accumulation and master weights), so autocast is
+        switched OFF inside: the handful of torch ops around the kernels (channel-embedding gather, positional resample, head, regularisers) must
+        not be re-typed behind the hand-written backward's back — with `use_amp=True` the model computes exactly what it computes without."""
+        with torch.autocast(device_type="cuda", enabled=False):
+            return self._forward_impl(x, chunk_name, training_chunks, init_first_layer, new_channel_init, **kwargs)
+
+    def _forward_impl(self, x: torch.Tensor, chunk_name: str, training_chunks: Optional[str] = None, init_first_layer=None,
+                      new_channel_init=None, **kwargs):
         if not x.is_cuda:
             raise RuntimeError("diverse_channel_vit_amd runs only on an MI355X: move the model and the batch to the GPU "
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ and is test infrastructure)")

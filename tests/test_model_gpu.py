@@ -803,8 +803,11 @@ def test_grad_scaler_flow_of_the_reference_trainer(gpu_device):
         for s in range(3):
             x, y = batches[s]
             opt.zero_grad()
-            out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
-            loss = ce(out, y) + extra
+            # the reference's flow wraps forward + loss in autocast when use_amp is set (trainer.py:861); the model switches it off inside
+            with torch.autocast("cuda", dtype=torch.float16, enabled=use_scaler):
+                out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+                assert out.dtype == torch.float32 and extra.dtype == torch.float32
+                loss = ce(out, y) + extra
             if scaler is None:
                 loss.backward()
                 dcv.clip_grad_norm_(model, 5.0)
