@@ -1338,6 +1338,94 @@ def test_dp_two_ranks_real_model_two_backwards(gpu_device, grad_dtype, overlap):
             assert worst <= (2e-3 if grad_dtype == "float32" else 8e-3), worst
 
 
+def _torch_ddp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import diverse_channel_vit_amd as dcv
+        meta, _ = load_golden("tiny_e2e")
+        ce = torch.nn.CrossEntropyLoss()
+        batches = {r: orc.make_batch(700 + r, 2, 3, 32, 5) for r in range(world)}
+        model, _ = build(meta, dev)
+        model.stochastic_weight_rounding = False
+        ddp = DDP(model, device_ids=[0], find_unused_parameters=True)  # trainer.py:1185, verbatim
+        opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.04, model=model)
+        x, y = batches[rank]
+        opt.zero_grad()
+        o, extra = ddp(x.to(dev), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+        (ce(o, y.to(dev)) + extra).backward()
+        torch.cuda.synchronize()
+        got = {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        opt.step()  # the fused optimiser reads the arena the DDP reducer wrote the averaged gradients back into
+        torch.cuda.synchronize()
+        w_after = model.feature_extractor.blocks[0].attn.qkv.weight.detach().double().cpu()
+        res = None
+        if rank == 0:
+            ref_model, _ = build(meta, dev)
+            ref_model.stochastic_weight_rounding = False
+            ropt = dcv.HipAdamW([p for p in ref_model.parameters() if p.requires_grad], lr=1e-3, weight_decay=0.04, model=ref_model)
+            ropt.zero_grad()
+            for r in range(world):
+                x, y = batches[r]
+                o, extra = ref_model(x.to(dev), "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+                ((ce(o, y.to(dev)) + extra) / world).backward()
+            worst = 0.0
+            for n, p in ref_model.named_parameters():
+                if p.grad is None:
+                    assert n not in got, n
+                    continue
+                ref = p.grad.detach().double().cpu()
+                worst = max(worst, (got[n] - ref).norm().item() / (ref.norm().item() + 1e-30))
+            ropt.step()
+            torch.cuda.synchronize()
+            wr = ref_model.feature_extractor.blocks[0].attn.qkv.weight.detach().double().cpu()
+            res = (worst, (w_after - wr).abs().max().item())
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_torch_ddp_wrapper_of_the_reference_trainer(gpu_device):
+    """Row a16 as the reference's trainer does it, unchanged: `DDP(model, device_ids=[local_rank], find_unused_parameters=True)`
+    (trainer.py:1185) around THIS model — two ranks (both on this box's one GPU, gloo), one step: torch's reducer walks the autograd graph
+    through the hand-written encoder node, copies the arena's gradient views into its buckets, averages, writes them back, and the fused
+    HipAdamW then steps from the arena.  Gradients equal the single-process average over both ranks' batches; the updated weights agree."""
+    import socket
+    import queue as _q
+    import time as _t
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_torch_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res, t0 = [], _t.time()
+    while len(res) < 2:
+        try:
+            res.append(q.get(timeout=2))
+        except _q.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or _t.time() - t0 > 500:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail(f"a rank exited with {dead} (or timed out)")
+    for p in procs:
+        p.join(60)
+    for rank, r in res:
+        if rank == 0:
+            worst, dw = r
+            print(f"torch DDP around the model: worst relative gradient difference vs single-process average {worst:.2e}, max |dW| after the step {dw:.2e}")
+            assert worst <= 2e-3 and dw <= 2.1e-3  # Adam's first step moves every weight by ~lr = 1e-3: a wrong gradient sign would show as 2e-3
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("grad_dtype,overlap", [("float32", True), ("bfloat16", True), ("float32", False)])
 def test_dp_two_ranks_rccl_two_gpus(gpu_device, grad_dtype, overlap):
