@@ -1368,7 +1368,10 @@ extern "C" int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile) {
     if (tile == DCV_TILE_WIDE) return legal384 ? DCV_TILE_WIDE : DCV_ERR_UNSUPPORTED;
     if (tile == DCV_TILE_NARROW) return DCV_TILE_NARROW;
     if (tile == DCV_TILE_PAIR) return epilogue != DCV_EPI_PATCH ? DCV_TILE_PAIR : DCV_ERR_UNSUPPORTED;
-    if (!legal384 || epilogue == DCV_EPI_GELU_BWD_BF16 || !(N >= 1152 || K >= 1536)) return DCV_TILE_NARROW;
+#ifndef DCV_WIDE_K_MIN
+#define DCV_WIDE_K_MIN 1536
+#endif
+    if (!legal384 || epilogue == DCV_EPI_GELU_BWD_BF16 || !(N >= 1152 || K >= DCV_WIDE_K_MIN)) return DCV_TILE_NARROW;
     // Both kernels are persistent, so a launch costs rounds x time per tile, rounds = ceil(tiles / workgroups).  A 256 x 384 tile takes
     // 2.3 (K >= 1536: the k-loop dominates) to 2.5 (K = 384: the epilogue dominates) times a 256 x 128 tile (measured from the per-round
     // times at M = 12 369 ... 100 416, tools/gemm_mid_m.py, tools/gemm_bench.py): wide wins when its rounds x that factor stay below

@@ -368,7 +368,7 @@ class DiChaViT(nn.Module):
         self.attn_bwd_fused = os.environ.get("DCV_ATTN_BWD_FUSED", "0") == "1"
         self.fuse_ln_min_tiles = int(os.environ.get("DCV_FUSE_LN_MIN_TILES", "96"))  # 256-row tiles below which the fusion does not pay (_run_forward)
         self.fuse_ln_fwd = os.environ.get("DCV_FUSE_LN", "1") != "0"  # forward LayerNorm inside the residual GEMMs' epilogue (dcv_gemm_nt_resid_ln; D = 384)
-        self.wgrad_scratch_release = os.environ.get("DCV_WGRAD_RELEASE", "1") != "0"  # hand a layer's private scratch back once its last reader is queued
+        self.wgrad_scratch_release = os.environ.get("DCV_WGRAD_RELEASE", "0") == "1"  # two streams: record_stream hand-back per layer (allocator stalls: see _run_backward_body)
         self.wgrad_group = os.environ.get("DCV_WGRAD_GROUP", "1") != "0"  # a block's four weight gradients in one launch (needs the private scratch)
         self._group_cache = {}
         self._stats_w = {}
@@ -1034,11 +1034,14 @@ class DiChaViT(nn.Module):
             if side is not None:
                 held.append(dict(L))  # the side stream may still be reading the saved activations
             L.clear()
-            if self.wgrad_scratch_release:
+            if self.wgrad_scratch_release or side is None:
                 # Everything in `held` — older layers' dz / dqkv / dxb and this layer's saved activations — has had its LAST reader queued
-                # (the block's weight-gradient launches above — grouped or one by one, they are all in their queue by now).  On one stream that is enough to hand the memory back; with the second stream
-                # the caching allocator is told who still reads it (record_stream: the block is reused only after that stream's work
-                # queued so far has completed).  Peak scratch then is what the second stream lags behind, not depth x 0.7 GB.
+                # (the block's weight-gradient launches above — grouped or one by one, they are all in their queue by now).  On ONE stream that
+                # is enough to hand the memory back, and it is done (peak scratch = one layer instead of depth x 0.7 GB).  With the
+                # second stream the hand-back needs record_stream (the allocator reuses the block only after that stream's queued work), and
+                # that is OFF by default: measured in round 4, the deferred frees make the caching allocator fall into its slow path once every
+                # few dozen steps — ONE step of ~1000 ms among 35 ms steps in 2 of 3 runs (gpurun r4u) — so the buffers are held until the
+                # streams join, as in round 3 (8.4 GB of scratch per backward for DiChaViT-S at bs 64, recycled step to step).
                 for t in held:
                     for v in (t.values() if isinstance(t, dict) else (t,)):
                         if side is not None and torch.is_tensor(v) and v.is_cuda:
