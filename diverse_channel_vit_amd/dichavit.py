@@ -359,7 +359,10 @@ class DiChaViT(nn.Module):
         self._grad_arena = None
         self._grad_scratch = None
         self._dp = None  # set by diverse_channel_vit_amd.dp.DataParallel
-        self.wgrad_stream = True  # the backward runs the weight-gradient GEMMs on a second HIP stream (_run_backward_body); False: one stream
+        # weight-gradient GEMMs on a second HIP stream (_run_backward_body)?  Default since round 4: NO.  With one grouped launch per block and the forward
+        # LayerNorm inside the residual GEMMs the one-stream step is 0.13-0.18 ms FASTER (35.57-35.66 against 35.67-35.79 ms, four alternating pairs on one
+        # box), needs no cross-stream events and hands every layer's scratch back at once; DCV_WGRAD_STREAM=1 / model.wgrad_stream = True selects two streams.
+        self.wgrad_stream = os.environ.get("DCV_WGRAD_STREAM", "0") == "1"
         self.wgrad_private_scratch = os.environ.get("DCV_WGRAD_PRIVATE", "1") != "0"  # per-layer scratch instead of reader waits (_run_backward_body)
         self.fused_proxy_loss = os.environ.get("DCV_FUSED_PROXY_LOSS", "1") != "0"  # the channel-embedding proxy term as one kernel (dcv_proxy_loss)
         # attention backward in one pass (dcv_attn_bwd_fused: 5 products, operands read once, dQ by an ordered, bit-reproducible hand-off).  Parity-green

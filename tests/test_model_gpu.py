@@ -1268,6 +1268,7 @@ def _two_rank_worker(rank, world, port, q, grad_dtype, overlap, backend="gloo"):
         batches = {(r, k): orc.make_batch(500 + 10 * r + k, 2, 3, 32, 5) for r in range(world) for k in range(2)}
         model, _ = build(meta, dev)
         model.stochastic_weight_rounding = False
+        model.wgrad_stream = (grad_dtype == "float32" and overlap)  # one of the three variants keeps the two-stream hand-over under test
         dp = dcv.DataParallel(model, min_bucket_bytes=1 << 18, grad_dtype=getattr(torch, grad_dtype), overlap=overlap)
         dp.broadcast_parameters(0)
         dp.hook_misc_params()  # before the first forward (INTEGRATION.md order)
@@ -1532,8 +1533,9 @@ class _EmulatedRccl:
         return _EmulatedWork(done, self.dev, self.broken)
 
 
+@pytest.mark.parametrize("two_streams", [True, False])
 @pytest.mark.parametrize("grad_dtype,overlap", [("float32", True), ("bfloat16", True), ("float32", False)])
-def test_dp_async_collectives_emulated_on_one_gpu(gpu_device, grad_dtype, overlap):
+def test_dp_async_collectives_emulated_on_one_gpu(gpu_device, grad_dtype, overlap, two_streams):
     """gloo is synchronous through the host and RCCL refuses two ranks on one device, so the ORDERING of the default
     data-parallel backward — buckets handed over from the weight-gradient stream while the backward continues, the autograd engine's
     end-of-backward callback as the only synchronisation — was never run against collectives that are really asynchronous and really
@@ -1550,6 +1552,7 @@ def test_dp_async_collectives_emulated_on_one_gpu(gpu_device, grad_dtype, overla
     def one_rank(rank, comm):
         model, _ = build(meta, dev)
         model.stochastic_weight_rounding = False
+        model.wgrad_stream = two_streams  # buckets handed over from the weight-gradient stream (True) or from the compute stream (the default)
         dp = dcv.DataParallel(model, min_bucket_bytes=1 << 18, grad_dtype=getattr(torch, grad_dtype), overlap=overlap, dist_module=comm)
         dp.hook_misc_params()
         snaps = []
