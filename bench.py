@@ -176,6 +176,11 @@ def main():
         print(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    # rehearsal hook (never used by the driver): DCV_BENCH_REHEARSAL=gloo runs the N > 1 code path with every rank on cuda:0 over gloo (RCCL refuses
+    # two ranks on one device) — a one-GPU box can then execute the multi-rank branches of this file (both exchange modes, watchdog, max over ranks)
+    rehearsal = os.environ.get("DCV_BENCH_REHEARSAL") == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -191,7 +196,10 @@ def main():
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29655"
         from diverse_channel_vit_amd.dp import DataParallel as _DP
         _DP.limit_rccl_channels(_DP.reserved_cus)  # before the communicator exists; see dp.py
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import diverse_channel_vit_amd as dcv
     from diverse_channel_vit_amd import hip
