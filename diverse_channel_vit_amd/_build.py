@@ -32,7 +32,9 @@ def _stale(target, deps):
 
 #: diagnostic translation units that REPLACE a product source in a variant build: the stamp / ablation / wrap / stagger harness of the GEMM kernels
 #: lives in tools/probes/gemm_instrumented.hip (the shipped csrc/gemm.hip carries none of it: VERDICT r3 item 8)
-INSTRUMENTED = {"gemm.hip": os.path.join(HERE, "..", "tools", "probes", "gemm_instrumented.hip")}
+INSTRUMENTED = {"gemm.hip": os.path.join(HERE, "..", "tools", "probes", "gemm_instrumented.hip"),
+                "attn.hip": os.path.join(HERE, "..", "tools", "probes", "attn_instrumented.hip"),
+                "attn_bwd.hip": os.path.join(HERE, "..", "tools", "probes", "attn_bwd_instrumented.hip")}  # -DDCV_FABL=<mask>: forward-loop ablations
 
 
 def build_variant(name: str, defines, verbose: bool = True, flags=(), instrumented=()) -> str:

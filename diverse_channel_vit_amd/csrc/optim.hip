@@ -122,6 +122,25 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// Scaled re-cast of parts of the operand copy (the pre-scaled-q attention path, attn.hip): desc[k] = {src offset (floats from src_base), dst
+// offset, count, scaled_count, kind}.  kind 0: dst_bf16[dst .. dst + count) = bf16(f * src) with f = scale for the first scaled_count elements and
+// 1 after them (the same rounding — nearest, or stochastic with the SAME per-element bits as dcv_cast_bf16_sr — as the copy it overwrites: one
+// rounding of scale * w, not a second rounding of the copy); kind 1: dst_f32[dst .. ) = f * src (the q part of a qkv bias).
+__global__ __launch_bounds__(256) void cast_scaled_ranges_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst_bf16,
+                                                                 float* __restrict__ dst_f32, const long long* __restrict__ desc, float scale,
+                                                                 const unsigned* __restrict__ seed_dev) {
+    const long long* d = desc + 5 * blockIdx.y;
+    const long long so = d[0], doff = d[1], count = d[2], nsc = d[3], kind = d[4];
+    const unsigned seed = seed_dev ? seed_dev[0] : 0u;
+    unsigned short* d16 = reinterpret_cast<unsigned short*>(dst_bf16);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const float v = src[so + i] * (i < nsc ? scale : 1.f);
+        if (kind == 1) dst_f32[doff + i] = v;
+        else if (seed_dev) d16[doff + i] = sr_bf16(v, (unsigned)(so + i), seed);
+        else dst_bf16[doff + i] = (bf16_t)v;
+    }
+}
+
 // sum of squares of a flat fp32 range, added to *acc (one atomic per block)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n4, long n, float* __restrict__ acc,
                                                     float* __restrict__ part) {
@@ -261,6 +280,16 @@ extern "C" int dcv_cast_transpose_bf16_sr(const float* src_base, void* dst_base,
     return DCV_OK;
 }
 
+extern "C" int dcv_cast_scaled_ranges(const float* src_base, void* dst_bf16, float* dst_f32, const long long* desc_dev, int n_desc,
+                                      int blocks_per_desc, float scale, const unsigned* seed_dev, void* stream) {
+    if (!src_base || !desc_dev || (!dst_bf16 && !dst_f32)) return DCV_ERR_NULL;
+    if (n_desc <= 0 || blocks_per_desc <= 0) return DCV_ERR_SHAPE;
+    hipLaunchKernelGGL(cast_scaled_ranges_kernel, dim3(blocks_per_desc, n_desc), dim3(256), 0, (hipStream_t)stream, src_base, (bf16_t*)dst_bf16,
+                       dst_f32, desc_dev, scale, seed_dev);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
 static long sumsq_grid(long n) {
     long grid = (n / 4 + 255) / 256;
     if (grid > 1024) grid = 1024;
@@ -305,7 +334,7 @@ extern "C" int dcv_fill_cls(float* x, const float* cls, const float* pos0, int B
     return DCV_OK;
 }
 
-extern "C" int dcv_version(void) { return 104; }  // 1.04: round 4 (dcv_attn_bwd_fused*; round 3 removed dcv_debug_hog and gave DCV_EPI_BIAS_RESID_F32 its aux2 factor)
+extern "C" int dcv_version(void) { return 105; }  // 1.04: round 4 (dcv_attn_bwd_fused*; round 3 removed dcv_debug_hog and gave DCV_EPI_BIAS_RESID_F32 its aux2 factor)
 
 extern "C" const char* dcv_error_string(int code) {
     switch (code) {

@@ -369,6 +369,11 @@ class DiChaViT(nn.Module):
         # but measured SLOWER than the dQ + dK/dV pair at the headline shape in round 4 (1100-1500 us against 865 us per layer: the hand-off's
         # ~5 us edge latency against a 3.6-iteration budget per edge, profiles/r04_x1_*), so it is opt-in: DCV_ATTN_BWD_FUSED=1 / model.attn_bwd_fused = True
         self.attn_bwd_fused = os.environ.get("DCV_ATTN_BWD_FUSED", "0") == "1"
+        # Pre-scaled q (round 4): the bf16 operand copy of W_q and the q part of the qkv bias are multiplied by scale * log2(e) when the copies are
+        # refreshed (one rounding, as before), so the qkv GEMM delivers q' = q scale log2 e; the three attention kernels then start their score
+        # accumulators at the row constants (-m, -LSE log2 e, -delta) and exp2 the accumulator directly: one vector instruction less per score in
+        # vector-issue-bound loops (dcv_attn_*_ps).  DCV_ATTN_PS=0 / model.attn_prescaled = False: the plain entries.  Not with the one-pass backward.
+        self.attn_prescaled = os.environ.get("DCV_ATTN_PS", "1") != "0"
         self.fuse_ln_min_tiles = int(os.environ.get("DCV_FUSE_LN_MIN_TILES", "96"))  # 256-row tiles below which the fusion does not pay (_run_forward)
         self.fuse_ln_fwd = os.environ.get("DCV_FUSE_LN", "1") != "0"  # forward LayerNorm inside the residual GEMMs' epilogue (dcv_gemm_nt_resid_ln; D = 384)
         self.wgrad_scratch_release = os.environ.get("DCV_WGRAD_RELEASE", "0") == "1"  # two streams: record_stream hand-back per layer (allocator stalls: see _run_backward_body)
@@ -447,6 +452,14 @@ class DiChaViT(nn.Module):
                 max_tiles = max(max_tiles, ((R + 63) // 64) * ((Cc + 63) // 64))
         self._tdesc = torch.tensor(desc, dtype=torch.int64, device=device)
         self._tdesc_n, self._tdesc_tiles = len(desc), max_tiles
+        # pre-scaled q: per block, the q rows of the qkv weight copy (kind 0, in place in the bf16 copy) and the qkv bias with its q part scaled (kind 1)
+        qdesc, Dm = [], self.dim
+        for li, b in enumerate(self.feature_extractor.blocks):
+            ow, ob = self._enc_off[self._w_index[id(b.attn.qkv.weight)]], self._enc_off[self._w_index[id(b.attn.qkv.bias)]]
+            qdesc.append([ow, ow, Dm * Dm, Dm * Dm, 0])
+            qdesc.append([ob, li * 3 * Dm, 3 * Dm, Dm, 1])
+        self._qdesc = torch.tensor(qdesc, dtype=torch.int64, device=device)
+        self._qbias = torch.empty(len(self.feature_extractor.blocks), 3 * Dm, dtype=torch.float32, device=device)
 
     def _bf(self, p, transposed=False):
         o = self._enc_off[self._w_index[id(p)]]
@@ -457,16 +470,23 @@ class DiChaViT(nn.Module):
             return v.view(p.numel() // R, R) if transposed else v.view(R, p.numel() // R)
         return v
 
-    def _refresh_operand_copies(self, stochastic: bool = False):
+    def _refresh_operand_copies(self, stochastic: bool = False, prescale_q: bool = False):
+        """prescale_q: W_q rows of the straight copy and the q part of the bias copy times scale * log2(e) (attn_prescaled); the transposed copy
+        stays unscaled (the input-gradient GEMM multiplies by it the gradient with respect to the unscaled q)."""
+        qc = (64 ** -0.5) * math.log2(math.e)
         if stochastic:
             if self._sr_seed is None or self._sr_seed.device != self._arena.device:
                 self._sr_seed = torch.full((1,), int(_cfg_get(self.cfg, "weight_rounding_seed", 1)), dtype=torch.int32, device=self._arena.device)
             hip.cast_bf16_sr(self._arena, self._bf16, self._enc_size, self._sr_seed)
             hip.cast_transpose_bf16_sr(self._arena, self._bf16_t, self._tdesc, self._tdesc_n, self._tdesc_tiles, self._sr_seed)
+            if prescale_q:
+                hip.cast_scaled_ranges(self._arena, self._bf16, self._qbias, self._qdesc, self._qdesc.shape[0], 64, qc, self._sr_seed)
             self._sr_seed.add_(1)  # a device-side bump: replays of a captured step draw fresh bits too
             return
         hip.cast_bf16(self._arena, self._bf16, self._enc_size)
         hip.cast_transpose_bf16(self._arena, self._bf16_t, self._tdesc, self._tdesc_n, self._tdesc_tiles)
+        if prescale_q:
+            hip.cast_scaled_ranges(self._arena, self._bf16, self._qbias, self._qdesc, self._qdesc.shape[0], 64, qc)
 
     def _new_grad_arena(self):
         """A zeroed flat gradient buffer for the encoder parameters.  The arena is reused when no parameter's .grad still aliases it
@@ -717,12 +737,13 @@ class DiChaViT(nn.Module):
         M = B * N
         dev = x.device
         bf, f32 = torch.bfloat16, torch.float32
-        self._refresh_operand_copies(stochastic=bool(save) and self.training and self.stochastic_weight_rounding)
+        ps = bool(self.attn_prescaled) and not self.attn_bwd_fused  # pre-scaled q for this forward AND its backward (kept in the saved state)
+        self._refresh_operand_copies(stochastic=bool(save) and self.training and self.stochastic_weight_rounding, prescale_q=ps)
         pe = fe.patch_embed
         # (channels, positions) structure of the embedding rows the tokeniser epilogue adds: (C, n) normally, (1, C*n) when the
         # positional table is per token (the reference's early-out, _pos_table)
         Ctok, ntok = tok if tok is not None else (C, n)
-        st = dict(B=B, C=C, n=n, N=N, M=M, save=save, tok=(Ctok, ntok))
+        st = dict(B=B, C=C, n=n, N=N, M=M, save=save, tok=(Ctok, ntok), ps=ps)
         # --- tokeniser: im2col -> MFMA GEMM with (+bias +channel_embed[c] +pos[i]) epilogue ---
         Xp = torch.empty(B * T, P * P, dtype=bf, device=dev)
         hip.im2col(x, ch_idx_dev, Xp, B, Ct, C, Hi, Wi, P, scale=st_scale, shift=st_shift)
@@ -776,7 +797,7 @@ class DiChaViT(nn.Module):
                 mean1, rstd1 = torch.empty(M, dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
                 hip.ln_fwd(xcur, blk.norm1.weight, blk.norm1.bias, u1, mean1, rstd1, M, D, LN_EPS)
             qkv = torch.empty(M, 3 * D, dtype=bf, device=dev)
-            hip.gemm_nt(u1, self._bf(blk.attn.qkv.weight), hip.EPI_BIAS_BF16, qkv, bias=blk.attn.qkv.bias)
+            hip.gemm_nt(u1, self._bf(blk.attn.qkv.weight), hip.EPI_BIAS_BF16, qkv, bias=self._qbias[bi] if ps else blk.attn.qkv.bias)
             o = torch.empty(M, D, dtype=bf, device=dev)
             lse = torch.empty(B, H, N, dtype=f32, device=dev)
             if tail:
@@ -784,7 +805,7 @@ class DiChaViT(nn.Module):
                 # every token-wise op after the attention needs the CLS rows alone, and the attention only the CLS query
                 # (keys and values still come from all tokens).  Same values and gradients as the reference, which computes
                 # — and then discards — the other rows.
-                hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale, nq=1)
+                hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale, nq=1, prescaled=ps)
                 o_c = o.view(B, N, D)[:, 0].contiguous()
                 x_c = xcur.view(B, N, D)[:, 0].contiguous()
                 xmid = torch.empty(B, D, dtype=f32, device=dev)
@@ -792,7 +813,7 @@ class DiChaViT(nn.Module):
                             **(dict(aux2=dsc[0], T=1) if dsc else {}))
                 R = B  # rows the rest of this block works on
             else:
-                hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale)
+                hip.attn_fwd(qkv, o, lse, B, N, H, D // H, scale, prescaled=ps)
                 o_c = None
                 xmid = torch.empty(M, D, dtype=f32, device=dev) if save else xcur
                 R = M
@@ -898,6 +919,7 @@ class DiChaViT(nn.Module):
         if dp is not None:
             dp.grad_ready(ga, *self._range_of([fe.norm.weight, fe.norm.bias]))
         scale = 64 ** -0.5
+        ps = bool(st.get("ps"))  # the forward of this pass ran with pre-scaled q: qkv holds q', the backward entries must match
         dz = torch.empty(M, 4 * D, dtype=bf, device=dev)
         du = torch.empty(M, D, dtype=bf, device=dev)
         dO = torch.empty(M, D, dtype=bf, device=dev)
@@ -1003,7 +1025,7 @@ class DiChaViT(nn.Module):
                 hip.gemm_nt(dxb, self._bf(blk.attn.proj.weight, True), hip.EPI_PLAIN_BF16, dO_c, **nt_kw)
                 hip.gemm_tn_acc(dxb, L["o_c"], g(blk.attn.proj.weight), g(blk.attn.proj.bias))
                 dO.view(B, N, D)[:, 0].copy_(dO_c)  # only the CLS rows of dO are read (nq = 1)
-                hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale, nq=1)
+                hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale, nq=1, prescaled=ps)
                 dx_c = dx
                 dx = torch.zeros(M, D, dtype=f32, device=dev)  # the residual gradient reaches the block input at the CLS rows only
                 dx.view(B, N, D)[:, 0].copy_(dx_c)
@@ -1016,10 +1038,10 @@ class DiChaViT(nn.Module):
                     dqkv = torch.empty_like(dqkv)
                 else:
                     before_write("dqkv")
-                if self.attn_bwd_fused:
+                if self.attn_bwd_fused and not ps:
                     hip.attn_bwd_fused(L["qkv"], L["o"], dO, L["lse"], dqkv, B, N, H, D // H, scale)
                 else:
-                    hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale)
+                    hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale, prescaled=ps)
             hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du, **nt_kw)
             wgrad_or_collect(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv", grouped)
             if grouped:

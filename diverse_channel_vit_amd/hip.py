@@ -50,6 +50,10 @@ _SIGS = {
     "dcv_attn_bwd_rows": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_dq_rows": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_dkdv_rows": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_fwd_rows_ps": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
+    "dcv_attn_bwd_rows_ps": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd_dq_rows_ps": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
+    "dcv_attn_bwd_dkdv_rows_ps": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_fused_ws_bytes": ([_i, _i, _i], C.c_size_t),
     "dcv_attn_bwd_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_fused_err_ptr": ([_vp, _i, _i, _i], _vp),
@@ -70,6 +74,7 @@ _SIGS = {
     "dcv_clip_scale": ([_vp, _l, _vp, _f, _vp], _i),
     "dcv_cast_bf16_sr": ([_vp, _vp, _l, _vp, _vp], _i),
     "dcv_cast_transpose_bf16_sr": ([_vp, _vp, _vp, _i, _i, _vp, _vp], _i),
+    "dcv_cast_scaled_ranges": ([_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp], _i),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -353,18 +358,24 @@ def ln_bwd(du, x, mean, rstd, gamma, dx_in, dx_out, dx_bf16, dgamma, dbeta, M, D
     _check(rc, "dcv_ln_bwd")
 
 
-def attn_fwd(qkv, o, lse, B, N, H, hd, scale, nq=None):
-    """nq: only the query rows [0, nq) of every (batch, head) are processed (default: all N)."""
+def attn_fwd(qkv, o, lse, B, N, H, hd, scale, nq=None, prescaled=False):
+    """nq: only the query rows [0, nq) of every (batch, head) are processed (default: all N).
+    prescaled: the q part of qkv holds q * scale * log2(e) (dcv_attn_fwd_rows_ps)."""
     nq_ = N if nq is None else nq
     prod = 2.0 * B * H * nq_ * N * hd  # one (query rows) x N x head_dim product over all (batch, head) pairs
     D_ = H * hd
     with _timer(lambda: ("attn_fwd3_kernel", f"B{B} N{N} H{H} Nq{nq_}", 2 * prod, 2 * prod, 2.0 * B * (N * 2 * D_ + nq_ * 2 * D_) + 4.0 * B * H * nq_)):
-        rc = load().dcv_attn_fwd_rows(_p(qkv), _p(o), _p(lse), B, N, N if nq is None else nq, H, hd, scale, _stream())
+        if prescaled:
+            rc = load().dcv_attn_fwd_rows_ps(_p(qkv), _p(o), _p(lse), B, N, N if nq is None else nq, H, hd, _stream())
+        else:
+            rc = load().dcv_attn_fwd_rows(_p(qkv), _p(o), _p(lse), B, N, N if nq is None else nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_fwd")
 
 
-def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None):
+def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None, prescaled=False):
     lib = load()
+    dq_fn = lib.dcv_attn_bwd_dq_rows_ps if prescaled else lib.dcv_attn_bwd_dq_rows
+    dkdv_fn = lib.dcv_attn_bwd_dkdv_rows_ps if prescaled else lib.dcv_attn_bwd_dkdv_rows
     nq = N if nq is None else nq
     if delta_ws.numel() < 2 * B * H * N or delta_ws.dtype != torch.float32:
         raise ValueError("attention backward workspace: 2*B*H*N float32 (-delta, then lse*log2e)")
@@ -373,10 +384,10 @@ def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None):
     # algorithmic credit: the backward is 4 products (dP, dV, dK, dQ); the S recomputation is executed
     # in both kernels but not credited: dQ kernel 1 credited / 3 executed, dK/dV kernel 3 credited / 4 executed
     with _timer(lambda: ("attn_bwd_dq2_kernel", f"B{B} N{N} H{H} Nq{nq}", 1 * prod, 3 * prod, 2.0 * B * (N * 3 * D_ + nq * 3 * D_))):  # also writes the row statistics
-        rc = lib.dcv_attn_bwd_dq_rows(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
+        rc = dq_fn(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dq")
     with _timer(lambda: ("attn_bwd_dkdv2_kernel", f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 1 * D_ + N * 2 * D_))):
-        rc = lib.dcv_attn_bwd_dkdv_rows(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
+        rc = dkdv_fn(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dkdv")
 
 
@@ -501,6 +512,12 @@ def cast_bf16_sr(src, dst, n, seed_dev):
 def cast_transpose_bf16_sr(src_base, dst_base, desc_dev, n_desc, max_tiles, seed_dev):
     _check(load().dcv_cast_transpose_bf16_sr(_p(src_base), _p(dst_base), _p(desc_dev), n_desc, max_tiles, _p(seed_dev), _stream()),
            "dcv_cast_transpose_bf16_sr")
+
+
+def cast_scaled_ranges(src_base, dst_bf16, dst_f32, desc_dev, n_desc, blocks_per_desc, scale, seed_dev=None):
+    """desc_dev int64 [n_desc][5] = {src offset, dst offset, count, scaled_count, kind (0: bf16 copy, 1: fp32 copy)} (dcv_cast_scaled_ranges)."""
+    _check(load().dcv_cast_scaled_ranges(_p(src_base), _p(dst_bf16), _p(dst_f32), _p(desc_dev), n_desc, blocks_per_desc, float(scale),
+                                         _p(seed_dev), _stream()), "dcv_cast_scaled_ranges")
 
 
 def proxy_loss_supported(C: int, D: int) -> bool:

@@ -163,6 +163,19 @@ int dcv_attn_bwd_dq_rows(const void* qkv, const void* o, const void* dO, const f
 int dcv_attn_bwd_dkdv_rows(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
                            int H, int head_dim, float scale, void* stream);
 
+/* Pre-scaled-q forms (round 4).  The q part of qkv holds q * scale * log2(e) — the caller scales the operand copy of W_q and the q part of the
+ * bias BEFORE the qkv GEMM (dcv_cast_scaled_ranges), so q is still rounded once.  The score accumulators then start at the row constants (-m,
+ * -LSE log2 e, -delta) and p = exp2(accumulator): one vector instruction less per score in each kernel.  Outputs as the plain entries: o, lse
+ * (natural log), dqkv with dQ the gradient with respect to the UNSCALED q.  The ws of the _ps pair carries -LSE log2 e: do not mix it with the
+ * plain pair's.  Replaces nothing in the reference (vit.py:128-133 computes (q @ k^T) * scale on a materialised matrix). */
+int dcv_attn_fwd_rows_ps(const void* qkv, void* o, float* lse, int B, int N, int Nq, int H, int head_dim, void* stream);
+int dcv_attn_bwd_rows_ps(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int Nq,
+                         int H, int head_dim, float scale, void* stream);
+int dcv_attn_bwd_dq_rows_ps(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N,
+                            int Nq, int H, int head_dim, float scale, void* stream);
+int dcv_attn_bwd_dkdv_rows_ps(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
+                              int H, int head_dim, float scale, void* stream);
+
 /* The same gradients in ONE pass (five N x N x 64 products instead of seven; Q, K, V, dO read once): one workgroup per 256 keys keeps
  * dK / dV in registers, dQ is summed across the key blocks of a (batch, head) by an ordered, bit-reproducible hand-off of f32 partial tiles
  * (no atomics) through ws.  ws: dcv_attn_bwd_fused_ws_bytes(B, N, H) bytes, 256-byte aligned, caller-owned scratch (statistics, flags and
@@ -233,6 +246,13 @@ int dcv_cast_transpose_bf16(const float* src_base, void* dst_base, const long lo
 int dcv_cast_bf16_sr(const float* src, void* dst, long n, const unsigned* seed_dev, void* stream);
 int dcv_cast_transpose_bf16_sr(const float* src_base, void* dst_base, const long long* desc_dev, int n_desc, int max_tiles,
                                const unsigned* seed_dev, void* stream);
+
+/* Scaled re-cast of parts of an operand copy.  desc_dev: device int64 [n_desc][5] = {src offset (floats from src_base), dst offset, count,
+ * scaled_count, kind}.  kind 0: dst_bf16[dst + i] = bf16(f_i * src[i]), kind 1: dst_f32[dst + i] = f_i * src[i], with f_i = scale for i <
+ * scaled_count and 1 after.  seed_dev NULL: round to nearest; else the stochastic rounding of dcv_cast_bf16_sr with the same per-element bits
+ * (offset from src_base), so the rewritten range is what that cast would have produced from scale * src.  blocks_per_desc: grid.x. */
+int dcv_cast_scaled_ranges(const float* src_base, void* dst_bf16, float* dst_f32, const long long* desc_dev, int n_desc, int blocks_per_desc,
+                           float scale, const unsigned* seed_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -796,6 +796,76 @@ def test_stochastic_cast_bit_exact_and_unbiased(gpu_device):
     assert mean_err.mean() < 0.35 * rtn_err.mean()
 
 
+@pytest.mark.parametrize("B,N,H,Nq,shift", [(2, 197, 3, None, 0.0), (1, 1569, 6, None, 0.0), (2, 289, 6, None, -40.0), (3, 130, 2, 5, 0.0),
+                                            (1, 1569, 6, 1, 0.0), (1, 64, 1, None, 25.0), (2, 257, 1, None, 0.0), (1, 17, 2, None, -3.0)])
+def test_attention_prescaled_q(hip, B, N, H, Nq, shift):
+    """dcv_attn_*_ps: the q part of qkv holds q * scale * log2(e); o, lse and dqkv (dQ with respect to the UNSCALED q) must equal the plain
+    definition.  `shift` adds a constant to every score of a query (through one k-aligned q component): -40 makes the first tile's maximum
+    strongly negative (the lazy reference maximum must start AT it, not at 0), +25 makes every score large; the spike below raises the maximum in
+    a late tile by more than the rescale threshold."""
+    D = H * 64
+    scale = 64 ** -0.5
+    c = scale * math.log2(math.e)
+    qkv = _bf(B, N, 3 * D, scale=1.5, seed=N + 3)
+    qkv[0, N // 2, :64] *= 4
+    qkv[0, N - 1, D:D + 64] = qkv[0, N // 2, :64]
+    if shift:
+        qkv[:, :, D + 63] = 1.0  # every key has 1 in its last component (head 0) ...
+        qkv[:, :, 63] = shift / scale  # ... so head 0's scores all move by `shift`
+    qs = qkv.clone()
+    qs[:, :, :D] = (qkv[:, :, :D].float() * c).to(torch.bfloat16)
+    qref = qs.float()
+    qref[:, :, :D] /= c  # what the kernels see, unscaled
+    qr = qref.clone().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, B, N, H, scale)
+    nq = N if Nq is None else Nq
+    o = torch.full((B, N, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lse = torch.full((B, H, N), float("nan"), device="cuda")
+    hip.attn_fwd(qs, o, lse, B, N, H, 64, scale, nq=Nq, prescaled=True)
+    _close(o[:, :nq], o_ref[:, :nq], 2e-2, 2e-2, "ps attn O")
+    _close(lse[:, :, :nq], lse_ref[:, :, :nq], 1e-4, 3e-3, "ps attn LSE")
+    dO = torch.full((B, N, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dO[:, :nq] = _bf(B, nq, D, seed=11)
+    (o_ref[:, :nq] * dO[:, :nq].float()).sum().backward()
+    dqkv = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ws = torch.empty(2, B, H, N, device="cuda")
+    hip.attn_bwd(qs, o, dO, lse, ws, dqkv, B, N, H, 64, scale, nq=Nq, prescaled=True)
+    assert torch.isfinite(dqkv.float()).all()
+    g = qr.grad.reshape(B, N, 3, D)
+    d = dqkv.float().reshape(B, N, 3, D)
+    for i, nm in enumerate(["dQ", "dK", "dV"]):
+        ref = g[:, :, i]
+        _close(d[:, :, i], ref, 3e-2, 3e-2 * ref.abs().max().item(), "ps " + nm)
+
+
+def test_cast_scaled_ranges(hip):
+    """dcv_cast_scaled_ranges rewrites ranges of an operand copy as the cast of scale * src: round-to-nearest, and stochastic with the SAME
+    per-element bits as dcv_cast_bf16_sr (so the rewritten range equals that cast applied to a scaled source); kind 1 writes the fp32 product."""
+    n = 4096 + 36
+    src = torch.randn(n, device="cuda") * 0.05
+    desc = torch.tensor([[128, 128, 1000, 1000, 0], [2048, 0, 300, 100, 1], [3000, 3000, 1132, 600, 0]], dtype=torch.int64, device="cuda")
+    sc = 0.18033688
+    scaled = src.clone()
+    scaled[128:1128] *= sc
+    scaled[3000:3600] *= sc
+    for seed in (None, 5):
+        sd = None if seed is None else torch.full((1,), seed, dtype=torch.int32, device="cuda")
+        want = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        got = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+        f32 = torch.full((300,), float("nan"), device="cuda")
+        if sd is None:
+            hip.cast_bf16(scaled, want, n)
+            hip.cast_bf16(src, got, n)
+        else:
+            hip.cast_bf16_sr(scaled, want, n, sd)
+            hip.cast_bf16_sr(src, got, n, sd)
+        hip.cast_scaled_ranges(src, got, f32, desc, 3, 4, sc, sd)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), seed
+        ref = src[2048:2348].clone()
+        ref[:100] *= sc
+        assert torch.equal(f32, ref)
+
+
 @pytest.mark.parametrize("B,N,H,Nq", [(2, 197, 3, 1), (1, 1569, 6, 1), (3, 130, 2, 5), (2, 289, 1, 130), (1, 64, 2, 64)])
 def test_attention_query_row_subset(hip, B, N, H, Nq):
     """dcv_attn_*_rows: only the query rows [0, Nq) are processed (the last block needs the CLS row only); keys / values are all N

@@ -20,6 +20,8 @@ dO = torch.randn(B, N, D, device="cuda").to(torch.bfloat16)
 if os.environ.get("AB_ZERO"):  # DVFS probe: all-zero operands draw less power (cdna guide rule 25); compare against random data
     qkv.zero_(); dO.zero_()
 dqkv = torch.empty_like(qkv)
+qkv_ps = qkv.clone()
+qkv_ps[:, :, :D] = (qkv[:, :, :D].float() * (0.125 * 1.4426950408889634)).to(torch.bfloat16)
 ws = torch.empty(2, B, H, N, device="cuda")
 p = lambda t: C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -54,13 +56,18 @@ def calls(h):
 
 
 def _calls(h):
-    return {"fwd": lambda: h.dcv_attn_fwd_rows(p(qkv), p(o), p(lse), B, N, N, H, 64, C.c_float(0.125), st),
-            "dq": lambda: h.dcv_attn_bwd_dq_rows(p(qkv), p(o), p(dO), p(lse), p(ws), p(dqkv), B, N, N, H, 64, C.c_float(0.125), st),
-            "dkdv": lambda: h.dcv_attn_bwd_dkdv_rows(p(qkv), p(dO), p(lse), p(ws), p(dqkv), B, N, N, H, 64, C.c_float(0.125), st)}
+    d = {"fwd": lambda: h.dcv_attn_fwd_rows(p(qkv), p(o), p(lse), B, N, N, H, 64, C.c_float(0.125), st),
+         "dq": lambda: h.dcv_attn_bwd_dq_rows(p(qkv), p(o), p(dO), p(lse), p(ws), p(dqkv), B, N, N, H, 64, C.c_float(0.125), st),
+         "dkdv": lambda: h.dcv_attn_bwd_dkdv_rows(p(qkv), p(dO), p(lse), p(ws), p(dqkv), B, N, N, H, 64, C.c_float(0.125), st)}
+    if hasattr(h, "dcv_attn_fwd_rows_ps"):  # the pre-scaled-q entries on the same operand with its q part scaled (same score distribution)
+        d.update({"fwd_ps": lambda: h.dcv_attn_fwd_rows_ps(p(qkv_ps), p(o), p(lse), B, N, N, H, 64, st),
+                  "dq_ps": lambda: h.dcv_attn_bwd_dq_rows_ps(p(qkv_ps), p(o), p(dO), p(lse), p(ws), p(dqkv), B, N, N, H, 64, C.c_float(0.125), st),
+                  "dkdv_ps": lambda: h.dcv_attn_bwd_dkdv_rows_ps(p(qkv_ps), p(dO), p(lse), p(ws), p(dqkv), B, N, N, H, 64, C.c_float(0.125), st)})
+    return d
 
 
 fns = [calls(h) for h in handles]
-KEYS = ("fwd", "dq", "dkdv", "fused")
+KEYS = tuple(os.environ["AB_ONLY"].split(",")) if os.environ.get("AB_ONLY") else ("fwd", "fwd_ps", "dq", "dq_ps", "dkdv", "dkdv_ps", "fused")  # AB_ONLY=fwd: ablation builds
 res = {(i, k): [] for i in range(len(libs)) for k in KEYS}
 outs = {}
 for rnd in range(int(os.environ.get("AB_ROUNDS", 12))):
@@ -84,4 +91,4 @@ for i, l in enumerate(libs):
     t = {k: res[(i, k)] for k in KEYS if res[(i, k)]}
     same = "" if i == 0 else f"  max|dO-ref| {float((outs[i][0] - outs[0][0]).abs().max()):.3g} max|dqkv-ref| {float((outs[i][1] - outs[0][1]).abs().max()):.3g}"
     print(f"{os.path.basename(l):40s} " + "  ".join(f"{k} {np.median(v):7.1f} (min {min(v):7.1f})" for k, v in t.items()) +
-          f"  sum(fwd,dq,dkdv) {sum(np.median(t[k]) for k in ('fwd', 'dq', 'dkdv')):7.1f} us" + same)
+          (f"  sum(fwd,dq,dkdv) {sum(np.median(t[k]) for k in ('fwd', 'dq', 'dkdv')):7.1f} us" if all(k in t for k in ('fwd', 'dq', 'dkdv')) else "") + same)

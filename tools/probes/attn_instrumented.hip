@@ -15,6 +15,13 @@
 //                   dP = dO . V^T, dV^T += dO^T . P, dK^T += Q^T . dS.   No atomics anywhere: results
 //                   are bitwise reproducible.
 #include "attn_common.hpp"
+// DIAGNOSTIC TWIN of csrc/attn.hip (tools/probes; built only by _build.build_variant(..., instrumented=("attn.hip",))): timing-only ablations of the
+// forward loop, selected by the bit mask DCV_FABL (outputs are WRONG for every non-zero mask):
+//   1 no K/V DMA inside the loop   2 no vmcnt wait / s_barrier   4 no LDS fragment reads (register operands)   8 no v_exp (p = s c - m c)
+//   256 no fma in front of v_exp (p = exp2(s): what a pre-scaled q and an accumulator that starts at -m c would leave)   16 no row-maximum pass   32 no QK MFMAs   64 no PV MFMAs   128 no conditional rescale of O
+#ifndef DCV_FABL
+#define DCV_FABL 0
+#endif
 
 namespace {
 
@@ -23,11 +30,6 @@ namespace {
 // Two earlier forms measured slower at the headline shape (tools/ab_bench.py): register-staged K/V with per-use address
 // arithmetic 436-448 us; a 4-stage ring with the NEXT tile's score MFMAs issued ahead of the softmax (register ping-pong,
 // 228 VGPRs, 2 waves per SIMD) 418-430 us; this one 397-405 us.  Occupancy beat intra-wave overlap.
-// PS ("pre-scaled q"): the q part of qkv already holds q * scale * log2(e) (the model scales the bf16 operand copy of W_q and the bias before the
-// qkv GEMM: one rounding, as before).  The score accumulators then START at -m (the lane's reference maximum, in log2 units) instead of zero, and
-// p = exp2(accumulator) needs no multiply-subtract: one vector instruction less per score (cdna guide, appendix B: row constants as the initial
-// accumulator).  minit holds -m in all 16 registers of an accumulator tuple and changes only when the reference maximum does.
-template <bool PS>
 #if DCV_WPE_FWD
 DCV_WAVES_PER_SIMD(DCV_WPE_FWD)
 #endif
@@ -88,19 +90,18 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
     f32x16 o[2];
     zero_acc(o[0]);
     zero_acc(o[1]);
-    float m = PS ? 0.f : -INFINITY, l = 0.f;  // PS: reference maximum in log2 units of the pre-scaled scores, set by the first tile
+    float m = -INFINITY, l = 0.f;
     const float c = a.scale * LOG2E;
-    constexpr float FWD_RESCALE_LOG2 = 8.f;
-    f32x16 minit;
-    zero_acc(minit);
 
     // COMPUTE = false: a wave without a valid query row only keeps the ring going; separate loops, not a branch in the loop
     // (attn_bwd.hip: the branch made the accumulators loop-carried phis resolved with register copies)
     auto tile = [&](auto MASKED, auto COMPUTE, int t, int slot) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) kv_issue(t + 2, slot == 0 ? 2 : slot - 1);
+        if (!(DCV_FABL & 2)) {
+            if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (!(DCV_FABL & 1) && t + 2 < nt) kv_issue(t + 2, slot == 0 ? 2 : slot - 1);
         if constexpr (!decltype(COMPUTE)::value) return;
         const int so = slot * KV_STAGE_BYTES;
         int ro[4], co[2][2];
@@ -114,10 +115,15 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            if constexpr (PS) s[kb] = minit;
-            else zero_acc(s[kb]);
+            zero_acc(s[kb]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s[kb] = mfma32(as_bf16x8(lds_read128(sKV, ro[ks] + kb * 4096)), qf[ks], s[kb]);
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 kf;
+                if (DCV_FABL & 4) { kf = qf[(ks + 1) & 3]; asm volatile("" : "+v"(kf)); }
+                else kf = as_bf16x8(lds_read128(sKV, ro[ks] + kb * 4096));
+                if (DCV_FABL & 32) { asm volatile("" ::"v"(kf)); s[kb][4 * ks] += 0.01f * (float)t; }
+                else s[kb] = mfma32(kf, qf[ks], s[kb]);
+            }
         }
         if constexpr (decltype(MASKED)::value) {
 #pragma unroll
@@ -126,52 +132,25 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r)
                     if (t * 64 + 32 * kb + acc_row(r, h) >= a.N) s[kb][r] = -INFINITY;
         }
-        float rsum = 0.f;
-        if constexpr (PS) {
-            // the accumulators are relative to the reference maximum already: mx = this tile's excess over it
-            float mx = s[0][0];
+        float mx = m;
+        if (!(DCV_FABL & 16)) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // first tile: the reference becomes the tile's maximum whatever its sign (the accumulators started at 0); later tiles: lazily, as below
-            if (t == 0 || __any(mx > FWD_RESCALE_LOG2)) {
-                const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-d);
-                l *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-                m += d;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) minit[r] = -m;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] -= d;
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[kb][r]);
-                    s[kb][r] = p;
-                    rsum += p;
-                }
-        } else {
-        float mx = m;
+        } else if (t == 0) mx = 8.f;
+        const float mc = mx * c;
+        float rsum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // Lazy reference maximum: m moves only when a tile's maximum exceeds it by more than FWD_RESCALE_LOG2 (log2 units: p <= 2^8 until it
-        // does — far from any fp32 / bf16 limit — and softmax is shift-invariant, so O / l is unchanged).  With 32 query rows per wave SOME row
-        // finds a new maximum in almost every tile, so the eager form rescaled O (an exp + 33 multiplies per lane) nearly always; this one
-        // after the first tile almost never.  (m = -inf before the first tile: the difference is +inf and alpha = 0.)
-        if (__any((mx - m) * c > FWD_RESCALE_LOG2)) {
+            for (int r = 0; r < 16; ++r) {
+                const float p = (DCV_FABL & 8) ? (s[kb][r] * c - mc) : (DCV_FABL & 256) ? __builtin_amdgcn_exp2f(s[kb][r]) : __builtin_amdgcn_exp2f(s[kb][r] * c - mc);
+                s[kb][r] = p;
+                rsum += p;
+            }
+        if (!(DCV_FABL & 128) && __any(mx > m)) {
             const float alpha = __builtin_amdgcn_exp2f((m - mx) * c);
             l *= alpha;
 #pragma unroll
@@ -179,16 +158,6 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
             m = mx;
-        }
-        const float mc = m * c;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] * c - mc);
-                s[kb][r] = p;
-                rsum += p;
-            }
         }
         l += rsum;
 #pragma unroll
@@ -198,8 +167,13 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
                 bf16x8 pf = acc_to_frag(s[kb], ss);
                 const int cc = kb * 4096 + ss * 2048;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = mfma32(join4(lds_tr_read(sKV, co[dt][0] + cc), lds_tr_read(sKV, co[dt][1] + cc)), pf, o[dt]);
+                for (int dt = 0; dt < 2; ++dt) {
+                    bf16x8 vf;
+                    if (DCV_FABL & 4) { vf = qf[(ss + dt) & 3]; asm volatile("" : "+v"(vf)); }
+                    else vf = join4(lds_tr_read(sKV, co[dt][0] + cc), lds_tr_read(sKV, co[dt][1] + cc));
+                    if (DCV_FABL & 64) { asm volatile("" ::"v"(vf), "v"(pf)); }
+                    else o[dt] = mfma32(vf, pf, o[dt]);
+                }
             }
     };
     using No = std::integral_constant<bool, false>;
@@ -231,33 +205,23 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
                 uint2 v = pack4_bf16(o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(op + 32 * dt + 8 * g + 4 * h) = v;
             }
-        if (h == 0) a.lse[((size_t)b * a.H + hh) * a.N + q] = (PS ? m * (1.f / LOG2E) : m * a.scale) + logf(l);
+        if (h == 0) a.lse[((size_t)b * a.H + hh) * a.N + q] = m * a.scale + logf(l);
     }
 }
 
 }  // namespace
 
-static int attn_fwd_launch(const void* qkv, void* o, float* lse, int B, int N, int Nq, int H, int head_dim, float scale, bool ps, void* stream) {
+extern "C" int dcv_attn_fwd_rows(const void* qkv, void* o, float* lse, int B, int N, int Nq, int H, int head_dim, float scale,
+                                 void* stream) {
     int rc = attn_check(qkv, B, N, H, head_dim);
     if (rc) return rc;
     if (!o || !lse) return DCV_ERR_NULL;
     if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
     AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, nullptr, lse, nullptr, nullptr, B, N, H, scale, Nq};
     const int grid = B * H * ((Nq + FWD_QTILE - 1) / FWD_QTILE);
-    if (ps) hipLaunchKernelGGL(attn_fwd3_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_fwd3_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_fwd3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
-}
-
-extern "C" int dcv_attn_fwd_rows(const void* qkv, void* o, float* lse, int B, int N, int Nq, int H, int head_dim, float scale,
-                                 void* stream) {
-    return attn_fwd_launch(qkv, o, lse, B, N, Nq, H, head_dim, scale, false, stream);
-}
-
-// the q part of qkv holds q * scale * log2(e) (see attn_fwd3_kernel<PS>); LSE comes out in the same natural-log units as dcv_attn_fwd_rows
-extern "C" int dcv_attn_fwd_rows_ps(const void* qkv, void* o, float* lse, int B, int N, int Nq, int H, int head_dim, void* stream) {
-    return attn_fwd_launch(qkv, o, lse, B, N, Nq, H, head_dim, 0.f, true, stream);
 }
 
 extern "C" int dcv_attn_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, int head_dim, float scale, void* stream) {
