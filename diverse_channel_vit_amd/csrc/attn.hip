@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = max_halves(mx);
             // first tile: the reference becomes the tile's maximum whatever its sign (the accumulators started at 0); later tiles: lazily, as below
             if (t == 0 || __any(mx > FWD_RESCALE_LOG2)) {
                 const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_halves(mx);
         // Lazy reference maximum: m moves only when a tile's maximum exceeds it by more than FWD_RESCALE_LOG2 (log2 units: p <= 2^8 until it
         // does — far from any fp32 / bf16 limit — and softmax is shift-invariant, so O / l is unchanged).  With 32 query rows per wave SOME row
         // finds a new maximum in almost every tile, so the eager form rescaled O (an exp + 33 multiplies per lane) nearly always; this one

@@ -71,6 +71,17 @@ __device__ __forceinline__ bf16x8 frag_cols(const char* tile, int rowbase, int s
     return join4(lo, hi);
 }
 
+// max(x of lane l, x of lane l ^ 32) by one v_permlane32_swap (gfx950) instead of __shfl_xor's ds_bpermute_b32: no LDS round trip and no s_waitcnt
+// lgkmcnt(0) — which in the forward loop also waited for every fragment read in flight — in the middle of a tile.  After the swap of x with itself one
+// result holds the lower half's values in both halves, the other the upper half's.
+__device__ __forceinline__ float max_halves(float x) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    float m;  // asm: fmaxf on values that arrive as integers makes hipcc canonicalise both operands first (two v_max x, x)
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    return m;
+}
+
 __device__ __forceinline__ void zero_acc(f32x16& x) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) x[r] = 0.f;

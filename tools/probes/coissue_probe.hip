@@ -6,6 +6,8 @@
 //   mode 3: every wave: burst of 8 MFMAs, then burst of 8 K vector instructions (E of every 8 are v_exp) — the phase structure of the attention loops;
 //           waves unsynchronised (no barrier), 1 / 2 / 3 waves per SIMD
 //   mode 4: mode 3 with one s_barrier per iteration (what a shared LDS ring does to the phases)
+//   mode 5: mode 3 with the attention loops' DEPENDENCIES: every vector instruction reads an accumulator of the burst's MFMAs, and the next
+//           iteration's MFMAs read an operand the vector burst produced (MFMA -> softmax -> MFMA); waves unsynchronised
 // Output: cycles (s_memtime) per iteration and per wave, against the issue-time model: MFMA 32 cycles, v_fma 4, v_exp 8 (or 16).
 // build: hipcc --offload-arch=gfx950 -O3 -o coissue_probe coissue_probe.hip ; run: ./coissue_probe
 #include <hip/hip_runtime.h>
@@ -60,6 +62,20 @@ __global__ __launch_bounds__(THREADS) void probe(int iters, unsigned long long* 
                     else VEXP(f[k & 7]);
                 }
             }
+        } else if constexpr (MODE == 5) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) MFMA(acc[u & 3]);
+#pragma unroll
+            for (int k = 0; k < 8 * K; ++k) {
+                if ((k % 8) < E) VEXP(f[k & 7]);
+                else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[k & 7]) : "v"(acc[k & 3][(k >> 2) & 15]), "v"(c2));
+            }
+            unsigned bw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(bw[i]) : "v"(f[2 * i]), "v"(f[2 * i + 1]));
+            typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+            const u32x4v bv = {bw[0], bw[1], bw[2], bw[3]};
+            b = __builtin_bit_cast(bf16x8, bv);
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) MFMA(acc[u & 3]);
@@ -148,5 +164,11 @@ int main() {
     run<4, 7, 0, 512>("  2 waves/SIMD, 56 v_fma", 2 * (256 + 224), 2 * 256.0);
     run<4, 14, 2, 512>("  2 waves/SIMD, 28 v_exp + 84 v_fma", 2 * (256 + 560), 2 * 560.0);
     run<4, 14, 2, 768>("  3 waves/SIMD, 28 v_exp + 84 v_fma", 3 * (256 + 560), 3 * 560.0);
+    printf("## mode 5: the bursts of mode 3 with MFMA -> vector -> MFMA dependencies (no barrier)\n");
+    run<5, 14, 2, 256>("  1 wave/SIMD, 28 v_exp + 84 v_fma on the accumulators", 256 + 560, 560);
+    run<5, 14, 2, 512>("  2 waves/SIMD, same", 2 * (256 + 560), 2 * 560.0);
+    run<5, 14, 2, 768>("  3 waves/SIMD, same", 3 * (256 + 560), 3 * 560.0);
+    run<5, 7, 0, 512>("  2 waves/SIMD, 56 v_fma on the accumulators", 2 * (256 + 224), 2 * 256.0);
+    run<5, 7, 0, 768>("  3 waves/SIMD, 56 v_fma on the accumulators", 3 * (256 + 224), 3 * 256.0);
     return 0;
 }
