@@ -433,8 +433,9 @@ def main():
         if pmc_path:
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            if dominant in pmc and dominant != "_meta":
-                v = pmc[dominant]
+            dom_key = dominant if dominant in pmc else dominant.split("<")[0]  # profiles older than the templated attention kernels
+            if dom_key in pmc and dom_key != "_meta":
+                v = pmc[dom_key]
                 roof["traffic"] = round(v["read_bytes_per_launch"] + v["written_bytes_per_launch"])
                 roof["traffic_unit"] = "bytes/launch (HBM, PMC: 2 x FETCH_SIZE + WRITE_SIZE)"
                 roof["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
@@ -453,8 +454,9 @@ def main():
                          "step_hbm_achieved_gbps": round(tot / (step_ms_now * 1e-3) / 1e9, 0),
                          "source": "HBM bytes: 2 x FETCH_SIZE + WRITE_SIZE summed over every kernel of a step, profiles/" + os.path.basename(pmc_path)}
         for r in table:  # per-symbol PMC traffic next to the algorithmic bytes (mean over the symbol's shapes in the PMC run)
-            if r["symbol"] in pmc and r["symbol"] != "_meta":
-                v = pmc[r["symbol"]]
+            key = r["symbol"] if r["symbol"] in pmc else r["symbol"].split("<")[0]
+            if key in pmc and key != "_meta":
+                v = pmc[key]
                 r["pmc_mbytes_per_launch"] = round((v["read_bytes_per_launch"] + v["written_bytes_per_launch"]) / 1e6, 1)
         # matrix-pipe utilisation per (symbol, shape) from the committed SQ-counter passes (tools/pmc_gemm.sh at the headline shapes):
         # mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), the share of wall cycles the MFMA pipes are busy

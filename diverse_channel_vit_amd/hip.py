@@ -364,7 +364,7 @@ def attn_fwd(qkv, o, lse, B, N, H, hd, scale, nq=None, prescaled=False):
     nq_ = N if nq is None else nq
     prod = 2.0 * B * H * nq_ * N * hd  # one (query rows) x N x head_dim product over all (batch, head) pairs
     D_ = H * hd
-    with _timer(lambda: ("attn_fwd3_kernel", f"B{B} N{N} H{H} Nq{nq_}", 2 * prod, 2 * prod, 2.0 * B * (N * 2 * D_ + nq_ * 2 * D_) + 4.0 * B * H * nq_)):
+    with _timer(lambda: (f"attn_fwd3_kernel<{'true' if prescaled else 'false'}>", f"B{B} N{N} H{H} Nq{nq_}", 2 * prod, 2 * prod, 2.0 * B * (N * 2 * D_ + nq_ * 2 * D_) + 4.0 * B * H * nq_)):
         if prescaled:
             rc = load().dcv_attn_fwd_rows_ps(_p(qkv), _p(o), _p(lse), B, N, N if nq is None else nq, H, hd, _stream())
         else:
@@ -383,10 +383,11 @@ def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None, presc
     D_ = H * hd
     # algorithmic credit: the backward is 4 products (dP, dV, dK, dQ); the S recomputation is executed
     # in both kernels but not credited: dQ kernel 1 credited / 3 executed, dK/dV kernel 3 credited / 4 executed
-    with _timer(lambda: ("attn_bwd_dq2_kernel", f"B{B} N{N} H{H} Nq{nq}", 1 * prod, 3 * prod, 2.0 * B * (N * 3 * D_ + nq * 3 * D_))):  # also writes the row statistics
+    tp = "<true>" if prescaled else "<false>"  # the symbols as rocprofv3 prints them (the kernels are templates on the pre-scaled-q form)
+    with _timer(lambda: ("attn_bwd_dq2_kernel" + tp, f"B{B} N{N} H{H} Nq{nq}", 1 * prod, 3 * prod, 2.0 * B * (N * 3 * D_ + nq * 3 * D_))):  # also writes the row statistics
         rc = dq_fn(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dq")
-    with _timer(lambda: ("attn_bwd_dkdv2_kernel", f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 1 * D_ + N * 2 * D_))):
+    with _timer(lambda: ("attn_bwd_dkdv2_kernel" + tp, f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 1 * D_ + N * 2 * D_))):
         rc = dkdv_fn(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dkdv")
 

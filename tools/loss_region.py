@@ -27,12 +27,12 @@ for _ in range(5):
 torch.cuda.synchronize()
 res = []
 for _ in range(10):
-    hip.set_profiler(True, only=["attn_fwd3_kernel", "attn_bwd_dq2_kernel"])
+    hip.set_profiler(True, only=["attn_fwd3_kernel<true>", "attn_bwd_dq2_kernel<true>", "attn_fwd3_kernel<false>", "attn_bwd_dq2_kernel<false>"])
     step()
     torch.cuda.synchronize()
     prof = hip.set_profiler(False)
-    fwd = [ev for k, v in prof.items() if k[0] == "attn_fwd3_kernel" for ev in v["ev"]]
-    bwd = [ev for k, v in prof.items() if k[0] == "attn_bwd_dq2_kernel" for ev in v["ev"]]
+    fwd = [ev for k, v in prof.items() if k[0].startswith("attn_fwd3_kernel") for ev in v["ev"]]
+    bwd = [ev for k, v in prof.items() if k[0].startswith("attn_bwd_dq2_kernel") for ev in v["ev"]]
     # launches are recorded in issue order per key; the full-size forward kernels come first, the Nq=1 one (last block) last
     last_fwd_end = max(fwd, key=lambda e: fwd[0][0].elapsed_time(e[1]))[1]
     first_bwd_start = min(bwd, key=lambda e: fwd[0][0].elapsed_time(e[0]))[0]
