@@ -1232,8 +1232,8 @@ __device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid) {
     for (int kt = 0; kt < nk; ++kt) {
         const int rem = nk - 1 - kt;  // younger stages in flight: min(rem, T3_STAGES - 2), 4 DMA pieces per wave each
         if (T3_STAGES >= 5 && rem >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (T3_STAGES >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (T3_STAGES >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (kt + T3_STAGES - 1 < nk) T3_ISSUE(kt + T3_STAGES - 1)  // (split between the SIMD partners as in gemm_nt_kernel, or issued behind the first fragment reads: +-1 %, not kept)
