@@ -1,8 +1,9 @@
 // Attention backward for head_dim 64 on gfx950 (see attn.hip for the orientation conventions): delta, dQ, dK/dV.
 // Compiled with -fno-slp-vectorize (see _build.py): hipcc's SLP packing of the dS arithmetic adds register-pair moves.
 #include "attn_common.hpp"
-// DIAGNOSTIC TWIN of csrc/attn_bwd.hip (tools/probes): timing-only ablations selected by DCV_FABL (outputs WRONG for every non-zero mask):
-//   256 no fma in front of v_exp (p = exp2(s))   512 dq: no (dp + ndlt) add either (ds = p dp)
+// DIAGNOSTIC TWIN of csrc/attn_bwd.hip (tools/probes; built only by _build.build_variant(..., instrumented=("attn_bwd.hip",))): timing-only ablations of
+// the dQ and dK/dV loops, selected by the bit mask DCV_FABL (outputs WRONG for every non-zero mask):
+//   1 no operand DMA inside the loop   2 no vmcnt wait / s_barrier   4 no LDS fragment reads (register operands)
 #ifndef DCV_FABL
 #define DCV_FABL 0
 #endif
@@ -46,6 +47,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs a) {
 #define DCV_DQ_STAGES 3
 #endif
 constexpr int DQ_STAGES = DCV_DQ_STAGES;
+// PS ("pre-scaled q", see attn.hip): the q part of qkv holds q * scale * log2(e); the S accumulator starts at -LSE * log2(e) and the dP accumulator
+// at -delta of the lane's query row (two loop-invariant register tuples), so p = exp2(S') and dS = p * dP' are one instruction each (cdna guide,
+// appendix B: row constants as the initial accumulator).  The workspace then carries -LSE * log2(e) for the dK/dV kernel, which starts ITS score
+// accumulator from those rows.
+template <bool PS>
 #if DCV_WPE_DQ
 DCV_WAVES_PER_SIMD(DCV_WPE_DQ)
 #endif
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
         ndlt += __shfl_xor(ndlt, 32, 64);  // the two lane halves hold the two 8-element groups of every 16
         if (h == 0 && q < a.Nq) {
             a.delta[sidx] = ndlt;
-            a.delta[(size_t)a.B * a.H * a.N + sidx] = lse2;
+            a.delta[(size_t)a.B * a.H * a.N + sidx] = PS ? -lse2 : lse2;
         }
     }
     const float c = a.scale * LOG2E;
@@ -139,15 +145,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     f32x16 dq[2];
     zero_acc(dq[0]);
     zero_acc(dq[1]);
+    f32x16 sinit, dpinit;  // PS only
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        sinit[r] = -lse2;
+        dpinit[r] = ndlt;
+    }
 
     // COMPUTE = false: a wave without a single valid query row only keeps the ring going (same DMA and barrier count).  The
     // two cases are separate LOOPS (below), not a branch inside one loop: with the branch inside, the accumulators became
     // loop-carried phis that hipcc resolved with a full register copy per tile (16 v_mov_b64) and twice the registers.
     auto tile = [&](auto MASKED, auto COMPUTE, int t, int slot) {
-        if (DQ_STAGES >= 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");  // younger: stage t+1
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
-        if (t + DQ_STAGES - 1 < nt) kv_issue(t + DQ_STAGES - 1, slot == 0 ? DQ_STAGES - 1 : slot - 1);  // (t + STAGES - 1) % STAGES
+        if (!(DCV_FABL & 2)) {
+            if (DQ_STAGES >= 3 && t + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KV_DMA_PER_WAVE) : "memory");  // younger: stage t+1
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
+        }
+        if (!(DCV_FABL & 1) && t + DQ_STAGES - 1 < nt) kv_issue(t + DQ_STAGES - 1, slot == 0 ? DQ_STAGES - 1 : slot - 1);  // (t + STAGES - 1) % STAGES
         if constexpr (!decltype(COMPUTE)::value) return;
         const int so = slot * KV_STAGE_BYTES;
         int ro[4], co[2][2];
@@ -161,8 +175,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
-            zero_acc(s);
-            zero_acc(dp);
+            if constexpr (PS) {
+                s = sinit;
+                dp = dpinit;
+            } else {
+                zero_acc(s);
+                zero_acc(dp);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 s = mfma32(as_bf16x8(lds_read128(sKV, ro[ks] + kb * 4096)), qf[ks], s);
@@ -170,11 +189,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float p = (DCV_FABL & 256) ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * c - lse2);
+                float p = PS ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * c - lse2);
                 if constexpr (decltype(MASKED)::value) {
                     if (t * 64 + 32 * kb + acc_row(r, h) >= a.N) p = 0.f;
                 }
-                s[r] = (DCV_FABL & 512) ? p * dp[r] : p * (dp[r] + ndlt);  // dS^T (the 1/sqrt(d) factor is applied once, to dQ)
+                s[r] = PS ? p * dp[r] : p * (dp[r] + ndlt);  // dS^T (the 1/sqrt(d) factor is applied once, to dQ)
             }
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
@@ -229,6 +248,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
 // the file is compiled with -fno-slp-vectorize: hipcc's SLP packing of the softmax-gradient arithmetic cost 48 v_mov per tile.)
 constexpr int DKV_STAGES = 4, DKV_STAGE_BYTES = 16384 + 1024;  // Q tile | dO tile | lse[64] | delta[64] | 512 B scratch
 constexpr int DKV_DMA_PER_WAVE = 5;
+// PS: q pre-scaled (see above); the workspace rows hold -LSE * log2(e) and are read straight into the score accumulator; dK leaves with 1 / log2(e)
+// (dK = scale dS^T Q = dS^T Q' / log2 e).
+template <bool PS>
 #if DCV_WPE_DKDV
 DCV_WAVES_PER_SIMD(DCV_WPE_DKDV)
 #endif
@@ -310,11 +332,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
 
     auto tile = [&](auto MASKED, auto COMPUTE, int t, int slot) {  // COMPUTE: see attn_bwd_dq2_kernel
         const int rem = nt - 1 - t;  // younger stages in flight: min(rem, 2)
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DKV_DMA_PER_WAVE) : "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DKV_DMA_PER_WAVE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
-        if (t + 3 < nt) issue(t + 3, (slot + 3) & 3);
+        if (!(DCV_FABL & 2)) {
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DKV_DMA_PER_WAVE) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DKV_DMA_PER_WAVE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
+        }
+        if (!(DCV_FABL & 1) && t + 3 < nt) issue(t + 3, (slot + 3) & 3);
         if constexpr (!decltype(COMPUTE)::value) return;
         const int so = slot * DKV_STAGE_BYTES;
         int ro[4], co[2][2];
@@ -330,14 +354,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s, dp;
             f32x4 l4[4];
-            zero_acc(s);
-            // the dP accumulator starts at -delta of its query rows (registers 4g..4g+3 = rows 8g+4h..+3: one 16-byte read)
+            if constexpr (!PS) zero_acc(s);
+            // the dP accumulator starts at -delta of its query rows (registers 4g..4g+3 = rows 8g+4h..+3: one 16-byte read); PS: the score
+            // accumulator likewise at -LSE log2(e)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 l4[g] = *reinterpret_cast<const f32x4*>(sQO + sto + (32 * qb + 8 * g) * 4);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(sQO + sto + 256 + (32 * qb + 8 * g) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dp[4 * g + e] = d4[e];
+                for (int e = 0; e < 4; ++e) {
+                    dp[4 * g + e] = d4[e];
+                    if constexpr (PS) s[4 * g + e] = l4[g][e];
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -348,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
             for (int g = 0; g < 4; ++g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float p = (DCV_FABL & 256) ? __builtin_amdgcn_exp2f(s[4 * g + e]) : __builtin_amdgcn_exp2f(s[4 * g + e] * c - l4[g][e]);
+                    float p = PS ? __builtin_amdgcn_exp2f(s[4 * g + e]) : __builtin_amdgcn_exp2f(s[4 * g + e] * c - l4[g][e]);
                     if constexpr (decltype(MASKED)::value) {
                         if (t * 64 + 32 * qb + 8 * g + 4 * h + e >= a.Nq) p = 0.f;  // query row does not exist
                     }
@@ -387,8 +415,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint2 v1 = pack4_bf16(dk[dt][4 * g] * a.scale, dk[dt][4 * g + 1] * a.scale, dk[dt][4 * g + 2] * a.scale,
-                                      dk[dt][4 * g + 3] * a.scale);
+                const float ks_ = PS ? (1.f / LOG2E) : a.scale;
+                uint2 v1 = pack4_bf16(dk[dt][4 * g] * ks_, dk[dt][4 * g + 1] * ks_, dk[dt][4 * g + 2] * ks_, dk[dt][4 * g + 3] * ks_);
                 uint2 v2 = pack4_bf16(dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
                 *reinterpret_cast<uint2*>(dkp + 32 * dt + 8 * g + 4 * h) = v1;
                 *reinterpret_cast<uint2*>(dvp + 32 * dt + 8 * g + 4 * h) = v2;
@@ -417,28 +445,59 @@ extern "C" int dcv_attn_bwd_delta(const void* o, const void* dO, const float* ls
     return DCV_OK;
 }
 
-extern "C" int dcv_attn_bwd_dq_rows(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N,
-                                    int Nq, int H, int head_dim, float scale, void* stream) {
+static int dq_launch(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int Nq, int H,
+                     int head_dim, float scale, bool ps, void* stream) {
     int rc = bwd_check(qkv, o, dO, lse, ws, B, N, H, head_dim);
     if (rc) return rc;
     if (!dqkv) return DCV_ERR_NULL;
     if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
     AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
-    hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(B * H * ((N + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid(B * H * ((N + 127) / 128));
+    if (ps) hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dq2_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
-
-extern "C" int dcv_attn_bwd_dkdv_rows(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
-                                      int H, int head_dim, float scale, void* stream) {
+static int dkdv_launch(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq, int H, int head_dim,
+                       float scale, bool ps, void* stream) {
     int rc = bwd_check(qkv, dO, dO, lse, (float*)ws, B, N, H, head_dim);
     if (rc) return rc;
     if (!dqkv) return DCV_ERR_NULL;
     if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
     AttnArgs a{(const bf16_t*)qkv, nullptr, (const bf16_t*)dO, (float*)lse, (float*)ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
-    hipLaunchKernelGGL(attn_bwd_dkdv2_kernel, dim3(B * H * ((N + 127) / 128)), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid(B * H * ((N + 127) / 128));
+    if (ps) hipLaunchKernelGGL(attn_bwd_dkdv2_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkdv2_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
+}
+
+extern "C" int dcv_attn_bwd_dq_rows(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N,
+                                    int Nq, int H, int head_dim, float scale, void* stream) {
+    return dq_launch(qkv, o, dO, lse, ws, dqkv, B, N, Nq, H, head_dim, scale, false, stream);
+}
+
+extern "C" int dcv_attn_bwd_dkdv_rows(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
+                                      int H, int head_dim, float scale, void* stream) {
+    return dkdv_launch(qkv, dO, lse, ws, dqkv, B, N, Nq, H, head_dim, scale, false, stream);
+}
+
+// Pre-scaled-q forms (the q part of qkv holds q * scale * log2(e), as dcv_attn_fwd_rows_ps reads it): same outputs as the plain entries — dQ is
+// the gradient with respect to the UNSCALED q (the operand the qkv input- and weight-gradient GEMMs expect).  The workspace of the _ps pair is
+// not interchangeable with the plain pair's (it carries -LSE log2 e).
+extern "C" int dcv_attn_bwd_dq_rows_ps(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N,
+                                       int Nq, int H, int head_dim, float scale, void* stream) {
+    return dq_launch(qkv, o, dO, lse, ws, dqkv, B, N, Nq, H, head_dim, scale, true, stream);
+}
+extern "C" int dcv_attn_bwd_dkdv_rows_ps(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
+                                         int H, int head_dim, float scale, void* stream) {
+    return dkdv_launch(qkv, dO, lse, ws, dqkv, B, N, Nq, H, head_dim, scale, true, stream);
+}
+extern "C" int dcv_attn_bwd_rows_ps(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N,
+                                    int Nq, int H, int head_dim, float scale, void* stream) {
+    int rc = dq_launch(qkv, o, dO, lse, ws, dqkv, B, N, Nq, H, head_dim, scale, true, stream);  // also fills the workspace
+    if (rc) return rc;
+    return dkdv_launch(qkv, dO, lse, ws, dqkv, B, N, Nq, H, head_dim, scale, true, stream);
 }
 
 extern "C" int dcv_attn_bwd_rows(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int Nq,
