@@ -407,6 +407,18 @@ def case_curve_jumpcp_b8(dichavit, loss_fn):
     _curve(dichavit, "curve100_jumpcp_s_b8", base_cfg(), 8, 224, 161, 8, 91, 100, 100)
 
 
+def case_curve_jumpcp_b16(dichavit, loss_fn):
+    """headline architecture at bs 16 over 100 DISTINCT batches (round 5): the per-step error is a batch mean, so the spread the
+    stochastic-rounding draw causes should fall like 1/sqrt(B) against the bs-8 curve; ~45 min on 6 cores, peak RSS recorded in
+    profiles/r05_x1_*."""
+    _curve(dichavit, "curve100_jumpcp_s_b16", base_cfg(), 8, 224, 161, 16, 191, 100, 100)
+
+
+def case_curve_jumpcp_b32(dichavit, loss_fn):
+    """the same at bs 32 (half the way to north_star's bs 64 on a log scale; ~50 GB of host memory and ~90 min of reference CPU time)."""
+    _curve(dichavit, "curve100_jumpcp_s_b32", base_cfg(), 8, 224, 161, 32, 291, 100, 100)
+
+
 def case_schedules(dichavit, loss_fn):
     """utils.cosine_scheduler (utils.py:563-574): the weight-decay schedule of trainer.py:217-228."""
     import utils as ref_utils
@@ -629,12 +641,12 @@ def case_init_stats(dichavit, loss_fn):
 
 
 CASES = dict(tokendrop=case_tokendrop, resolution=case_resolution, schedules=case_schedules, loss_fns=case_loss_fns, tiny=case_tiny, so2sat=case_so2sat, jumpcp=case_jumpcp, hcs=case_hcs,
-             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, curve_jumpcp_b8=case_curve_jumpcp_b8, curve_so2sat_distinct=case_curve_so2sat_distinct, resume=case_resume,
+             chammi=case_chammi, eval=case_eval, curve_so2sat=case_curve_so2sat, curve_jumpcp=case_curve_jumpcp, curve_jumpcp_b8=case_curve_jumpcp_b8, curve_jumpcp_b16=case_curve_jumpcp_b16, curve_jumpcp_b32=case_curve_jumpcp_b32, curve_so2sat_distinct=case_curve_so2sat_distinct, resume=case_resume,
              chammi_hcs=case_chammi_hcs, jumpcp_b16=case_jumpcp_b16, base64=case_base64, resolution_quirk=case_resolution_quirk,
              hcs_proj=case_hcs_proj, init_stats=case_init_stats, base32_train=case_base32_train, nochannel_embed=case_nochannel_embed, drop_path=case_drop_path)
 
 if __name__ == "__main__":
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
     torch.manual_seed(0)
     dichavit, loss_fn = load_reference()
     for c in (sys.argv[1:] or list(CASES)):
