@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char sQO[DKV_STAGES * DKV_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nkt = (a.N + 127) / 128;
+    const int nkt = (a.N - a.key_lo + 127) / 128;  // key tiles launched: keys [key_lo, N)
     const int BH = a.B * a.H;
     int bh, kt;
     if ((BH & 7) == 0) {
@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         bh = blockIdx.x / nkt;
         kt = blockIdx.x % nkt;
     }
+    kt += a.key_lo / 128;
     const int b = bh / a.H, hh = bh % a.H;
     const int D = a.H * 64;
     const size_t rs = (size_t)3 * D;
@@ -454,10 +455,22 @@ static int dkdv_launch(const void* qkv, const void* dO, const float* lse, const 
     if (rc) return rc;
     if (!dqkv) return DCV_ERR_NULL;
     if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
+#if DCV_DKDV_FORM == 3
+    if (ps) return dcv_dkdv3_launch(qkv, dO, lse, ws, dqkv, B, N, Nq, H, scale, (hipStream_t)stream);  // attn_bwd3.hip (round 5); same sums, same order
+#endif
     AttnArgs a{(const bf16_t*)qkv, nullptr, (const bf16_t*)dO, (float*)lse, (float*)ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
     const dim3 grid(B * H * ((N + 127) / 128));
     if (ps) hipLaunchKernelGGL(attn_bwd_dkdv2_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_bwd_dkdv2_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+__attribute__((visibility("hidden"))) int dcv_dkdv2_range(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq, int H, float scale, int key_lo,
+                    hipStream_t stream) {
+    AttnArgs a{(const bf16_t*)qkv, nullptr, (const bf16_t*)dO, (float*)lse, (float*)ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
+    a.key_lo = key_lo;
+    hipLaunchKernelGGL(attn_bwd_dkdv2_kernel<true>, dim3(B * H * ((N - key_lo + 127) / 128)), dim3(256), 0, stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

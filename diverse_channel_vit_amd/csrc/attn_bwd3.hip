@@ -1,238 +1,40 @@
-// Attention backward, dK / dV, third form (head_dim 64, pre-scaled q): ONE wave per SIMD owning the whole 512-entry register file,
-// 64 keys per wave (cdna guide, appendix B "Attention backward": one workgroup = 4 waves = 256 keys of one (batch, head); each wave keeps
-// dK^T and dV^T of its 64 keys in accumulator registers while the workgroup sweeps the 32-row query slices).
+// Attention backward, dK / dV, third form (head_dim 64, pre-scaled q): ONE wave per SIMD owning the whole 512-entry register file, 64 keys per
+// wave, persistent workgroups (cdna guide, appendix B "Attention backward" and "4-wave, one-wave-per-SIMD, persistent structure": one workgroup =
+// 4 waves = 256 keys of one (batch, head); each wave keeps dK^T and dV^T of its 64 keys in accumulator registers while the workgroup sweeps the
+// 32-row query slices).
 //
 // Why (round 5): the second form (attn_bwd.hip, 32 keys per wave, two waves per SIMD) runs at matrix + vector time (MFMA busy 0.49, co-execution
 // 0.13): every 32 x 32 score block re-reads its Q / dO fragments from LDS (32 LDS instructions per 16 MFMAs and wave, eight waves per CU).  With 64
 // keys per wave one set of Q / dO fragments (row reads for S and dP, transposed reads for dV^T and dK^T) feeds TWO key blocks: half the LDS reads
-// and half the LDS-DMA pieces per score, and the score / softmax-gradient arithmetic of one 32 x 32 block sits in the MFMA shadow of its
-// neighbours (software pipeline below) instead of depending on a second wave's phase.
+// and half the LDS-DMA pieces per score, and the vector work of one 32 x 32 block sits in the MFMA shadow of its neighbours (software pipeline
+// below) instead of depending on a second wave's phase.  Same summation order as the second form: bit-identical outputs.
+//
+// A UNIT is one 32-query x 32-key block of one wave: (tile t, slice qb, key block kb), four units per 64-query tile in the order (0,0) (0,1) (1,0)
+// (1,1).  Step u of the stream issues 16 MFMAs — S' and dP' of unit u+1 (8), then dV^T and dK^T of unit u-1 (8) — and, in the 16 gaps between
+// them, the vector work of unit u (16 x {v_exp, v_mul}, 16 v_cvt_pk) plus one or two LDS fragment reads (<= 5 single-issue fillers per gap, at
+// most one of them a v_exp: MI355X_MICROARCH, cycle constants).  MFMAs are inline asm so that their operands sit where the design needs them —
+// dK^T / dV^T (128 registers) and the K / V fragments (64 + 64 of the next item) in the accumulator file, S' / dP' in arch VGPRs where the vector
+// instructions read them — and every gap is fenced with sched_barrier(0), every filler value pinned by an empty asm: the order below IS the
+// instruction stream.  Hazards hipcc does not see inside asm (cdna guide 5.7): an S' / dP' chain is finished 8 MFMAs (256 cycles) before its
+// first vector read; P / dS fragments are written one step before the MFMAs that read them; the accumulators are read behind s_nop.
+//
+// Persistent: with one workgroup per CU nothing hides a workgroup's prologue (K / V fragments, first Q / dO stages: 11 k cycles measured) and
+// epilogue (dK / dV stores at a row stride: 9 k cycles) — 23 % of the non-persistent form.  Here a workgroup walks ITEMS (batch-head, 256-key
+// block) and every byte an item needs from or sends to HBM moves DURING an item, a few pieces per tile: the Q / dO ring runs across item seams
+// (the cursor issues the next item's first stages during the last tiles); the next item's K / V rows arrive by LDS-DMA in a per-wave 16 KB
+// region R (tiles nt-12 .. nt-5) and become register fragments at the seam; dK / dV leave the accumulators at the seam into the same region (bf16,
+// row = key) and go to HBM as whole 128-byte rows, two store instructions per tile over the next item's first eight tiles.  (All 256 workgroups
+// run in lockstep: with the loads and stores AT the seam every CU hit HBM at once while no CU computed — 68 of 418 us, timing-only ablation.)
 #include "attn_common.hpp"
 
 namespace {
 
-constexpr int K3_STAGES = 4, K3_STAGE_BYTES = 16384 + 1024;  // Q tile | dO tile | -LSE log2e [64] | -delta[64] | 512 B scratch
-constexpr int K3_DMA_PER_WAVE = 5;
-constexpr int K3_KEYS = 256;  // keys per workgroup
+constexpr int K3_KEYS = 256;  // keys per workgroup item
+constexpr int P3_STAGES = 5, P3_STAGE_BYTES = 16384 + 1024, P3_DMA = 5;  // stage: Q tile | dO tile | -LSE log2e [64] | -delta [64] | 512 B scratch
+constexpr int P3_R_BYTES = 16384;  // per-wave region R: next item's K tile | V tile (swizzled like a ring tile), then this item's dK | dV tiles
 
-#ifndef DCV_K3_PIPE
-#define DCV_K3_PIPE 1
-#endif
-
-__attribute__((amdgpu_waves_per_eu(1, 1)))
-__global__ __launch_bounds__(256) void attn_bwd_dkdv3_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char sQO[K3_STAGES * K3_STAGE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nkt = (a.N + K3_KEYS - 1) / K3_KEYS;
-    const int BH = a.B * a.H;
-    int bh, kt;
-    if ((BH & 7) == 0) {
-        int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        bh = (slot / nkt) * 8 + xcd;
-        kt = slot % nkt;
-    } else {
-        bh = blockIdx.x / nkt;
-        kt = blockIdx.x % nkt;
-    }
-    const int b = bh / a.H, hh = bh % a.H;
-    const int D = a.H * 64;
-    const size_t rs = (size_t)3 * D;
-    const bf16_t* Qb = a.qkv + (size_t)b * a.N * rs + hh * 64;
-    const bf16_t* Kb = Qb + D;
-    const bf16_t* Vb = Qb + 2 * D;
-    const bf16_t* dOb = a.dO + (size_t)b * a.N * D + hh * 64;
-    // waves 0/2 fetch the -LSE log2e rows, waves 1/3 the -delta rows; waves 2,3 write theirs to the scratch slot (uniform DMA count per wave)
-    const float* statb = a.delta + ((wave & 1) ? 0 : (size_t)a.B * a.H * a.N) + ((size_t)b * a.H + hh) * a.N;
-    const int nt = (a.Nq + 63) / 64;
-
-    const int rowl = 16 * wave + (lane >> 3);
-    const int lc8[2] = {((lane & 7) ^ swz64(rowl)) * 8, ((lane & 7) ^ swz64(rowl + 8)) * 8};
-    const unsigned vq0 = (unsigned)(((size_t)rowl * rs + lc8[0]) * 2), vq1 = (unsigned)(((size_t)(rowl + 8) * rs + lc8[1]) * 2);
-    const unsigned vo0 = (unsigned)(((size_t)rowl * D + lc8[0]) * 2), vo1 = (unsigned)(((size_t)(rowl + 8) * D + lc8[1]) * 2);
-    const unsigned vs = (unsigned)lane * 4;
-    const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_addr(sQO));
-    const unsigned smem_base = smem0 + 16 * wave * 128;
-    const unsigned stat_dst = smem0 + 16384 + (wave & 1) * 256 + (wave >> 1) * 512;
-    auto issue = [&](int t, int slot) {
-        const unsigned sb = smem_base + slot * K3_STAGE_BYTES;
-        const bf16_t* qt = Qb + (size_t)t * 64 * rs;  // scalar bases
-        const bf16_t* ot = dOb + (size_t)t * 64 * D;
-        const float* st = statb + t * 64;
-        unsigned q0 = vq0, q1 = vq1, o0 = vo0, o1 = vo1, s0 = vs;
-        if (t * 64 + 64 > a.Nq) {  // partial tile: clamp query rows >= Nq to Nq-1 (valid data; their P is zeroed in the masked tile body)
-            const int r0 = min(t * 64 + rowl, a.Nq - 1) - t * 64, r1 = min(t * 64 + rowl + 8, a.Nq - 1) - t * 64;
-            q0 = (unsigned)(((size_t)r0 * rs + lc8[0]) * 2);
-            q1 = (unsigned)(((size_t)r1 * rs + lc8[1]) * 2);
-            o0 = (unsigned)(((size_t)r0 * D + lc8[0]) * 2);
-            o1 = (unsigned)(((size_t)r1 * D + lc8[1]) * 2);
-            s0 = (unsigned)(min(t * 64 + lane, a.Nq - 1) - t * 64) * 4;
-        }
-        glds16s(qt, q0, sb);
-        glds16s(ot, o0, sb + 8192);
-        glds16s(qt, q1, sb + 1024);
-        glds16s(ot, o1, sb + 8192 + 1024);
-        glds4s(st, s0, stat_dst + slot * K3_STAGE_BYTES);
-    };
-
-    const int key0 = kt * K3_KEYS + wave * 64;  // this wave's first key
-    const bool active = key0 < a.N;             // a wave without a single valid key only keeps the ring going
-    bf16x8 kf[2][4], vf[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int kc = min(key0 + 32 * kb + r32, a.N - 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf[kb][ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Kb + (size_t)kc * rs + 16 * ks + 8 * h));
-            vf[kb][ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Vb + (size_t)kc * rs + 16 * ks + 8 * h));
-        }
-    }
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(kf[kb][ks]), "v"(vf[kb][ks]));  // hipcc's wait for these loads sits here
-    for (int st = 0; st < K3_STAGES - 1; ++st)
-        if (st < nt) issue(st, st);
-    const LaneOffs lo = lane_offs(lane);
-    f32x16 dk[2][2], dv[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            zero_acc(dk[kb][dt]);
-            zero_acc(dv[kb][dt]);
-        }
-
-    auto tile = [&](auto MASKED, auto COMPUTE, int t, int slot) {
-        const int rem = nt - 1 - t;  // younger stages in flight: min(rem, 2)
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * K3_DMA_PER_WAVE) : "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K3_DMA_PER_WAVE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone is done with tile t-1 -> its buffer is free
-        if (t + 3 < nt) issue(t + 3, (slot + 3) & 3);
-        if constexpr (!decltype(COMPUTE)::value) return;
-        const int so = slot * K3_STAGE_BYTES;
-        int ro[4], co[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) ro[ks] = lo.rows[ks] + so;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            co[dt][0] = lo.cols[dt][0] + so;
-            co[dt][1] = lo.cols[dt][1] + so;
-        }
-        const int sto = so + 16384 + 16 * h;  // this lane-half's 4 consecutive query rows inside an 8-row group
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            f32x16 s[2], dp[2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(sQO + sto + (32 * qb + 8 * g) * 4);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(sQO + sto + 256 + (32 * qb + 8 * g) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s[0][4 * g + e] = l4[e];
-                    s[1][4 * g + e] = l4[e];
-                    dp[0][4 * g + e] = d4[e];
-                    dp[1][4 * g + e] = d4[e];
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 qf = as_bf16x8(lds_read128(sQO, ro[ks] + qb * 4096));
-                const bf16x8 dof = as_bf16x8(lds_read128(sQO, ro[ks] + 8192 + qb * 4096));
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    s[kb] = mfma32(qf, kf[kb][ks], s[kb]);
-                    dp[kb] = mfma32(dof, vf[kb][ks], dp[kb]);
-                }
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float p = __builtin_amdgcn_exp2f(s[kb][r]);
-                    if constexpr (decltype(MASKED)::value) {
-                        if (t * 64 + 32 * qb + acc_row(r, h) >= a.Nq) p = 0.f;  // query row does not exist
-                    }
-                    s[kb][r] = p;
-                    dp[kb][r] = p * dp[kb][r];  // dS = P * (dP - delta)
-                }
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const int cc = qb * 4096 + ss * 2048;
-                bf16x8 pf[2], dsf[2];
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    pf[kb] = acc_to_frag(s[kb], ss);
-                    dsf[kb] = acc_to_frag(dp[kb], ss);
-                }
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const bf16x8 doT = join4(lds_tr_read(sQO, co[dt][0] + 8192 + cc), lds_tr_read(sQO, co[dt][1] + 8192 + cc));
-                    const bf16x8 qT = join4(lds_tr_read(sQO, co[dt][0] + cc), lds_tr_read(sQO, co[dt][1] + cc));
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
-                        dv[kb][dt] = mfma32(doT, pf[kb], dv[kb][dt]);
-                        dk[kb][dt] = mfma32(qT, dsf[kb], dk[kb][dt]);
-                    }
-                }
-            }
-        }
-    };
-    using No = std::integral_constant<bool, false>;
-    using Yes = std::integral_constant<bool, true>;
-    const int nfull = a.Nq / 64;
-    if (active) {
-        for (int t = 0; t < nfull; ++t) tile(No{}, Yes{}, t, t & 3);
-        if (nfull < nt) tile(Yes{}, Yes{}, nfull, nfull & 3);
-    } else {
-        for (int t = 0; t < nfull; ++t) tile(No{}, No{}, t, t & 3);
-        if (nfull < nt) tile(Yes{}, No{}, nfull, nfull & 3);
-    }
-
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int key = key0 + 32 * kb + r32;
-        if (key < a.N) {
-            bf16_t* dkp = a.dqkv + ((size_t)b * a.N + key) * rs + D + hh * 64;
-            bf16_t* dvp = dkp + D;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float ks_ = 1.f / LOG2E;
-                    uint2 v1 = pack4_bf16(dk[kb][dt][4 * g] * ks_, dk[kb][dt][4 * g + 1] * ks_, dk[kb][dt][4 * g + 2] * ks_, dk[kb][dt][4 * g + 3] * ks_);
-                    uint2 v2 = pack4_bf16(dv[kb][dt][4 * g], dv[kb][dt][4 * g + 1], dv[kb][dt][4 * g + 2], dv[kb][dt][4 * g + 3]);
-                    *reinterpret_cast<uint2*>(dkp + 32 * dt + 8 * g + 4 * h) = v1;
-                    *reinterpret_cast<uint2*>(dvp + 32 * dt + 8 * g + 4 * h) = v2;
-                }
-        }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// The software-pipelined form.  A UNIT is one 32-query x 32-key block of one wave: (tile t, slice qb, key block kb), four units per 64-query
-// tile in the order (0,0) (0,1) (1,0) (1,1).  Step u of the stream issues 16 MFMAs — S' and dP' of unit u+1 (8), then dV^T and dK^T of unit
-// u-1 (8) — and, in the 16 gaps between them, the vector work of unit u (16 x {v_exp, v_mul}, 16 v_cvt_pk) plus one or two LDS fragment reads
-// (<= 5 single-issue fillers per gap, at most one of them a v_exp: MI355X_MICROARCH, cycle constants).  MFMAs are inline asm so that their
-// accumulators sit where the design needs them — dK^T / dV^T (128 registers) and the K / V fragments (64) in the accumulator file, S' / dP' in
-// arch VGPRs where the vector instructions read them — and every gap is fenced with sched_barrier(0): the order below IS the instruction stream.
-// Hazards hipcc does not see inside asm (cdna guide 5.7): an S' / dP' chain is finished 8 MFMAs (256 cycles) before its first vector read; P / dS
-// fragments are written one step before the MFMAs that read them; the accumulators are read after the loop behind s_nop.
-constexpr int P3_STAGES = 5, P3_STAGE_BYTES = 16384 + 1024, P3_DMA = 5;
-
-__device__ __forceinline__ void mfma_vv(f32x16& d, const bf16x8& a, const bf16x8& b) {  // d += a b   (d in arch VGPRs, b = K / V fragment in AGPRs)
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
-}
-__device__ __forceinline__ void mfma_vc(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c) {  // d = a b + c
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
-}
-__device__ __forceinline__ void mfma_aa(f32x16& d, const bf16x8& a, const bf16x8& b) {  // d += a b   (d in AGPRs)
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
-}
 #ifdef DCV_K3_STAMP  // diagnostic build only (tools/attn3_stamps.py): cycle stamps of wave 0 of every workgroup; never in the product library
-__device__ unsigned long long k3_stamps[8192 * 8];
+__device__ unsigned long long k3_stamps[1024 * 8];
 #define K3_NOW() __builtin_amdgcn_s_memtime()
 #endif
 #define P3_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -244,32 +46,55 @@ __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {  // one v_c
     v[1] = (bf16_t)hi;
     return __builtin_bit_cast(unsigned, v);
 }
+__device__ __forceinline__ void mfma_vv(f32x16& d, const bf16x8& a, const bf16x8& b) {  // d += a b   (d in arch VGPRs, b = K / V fragment in AGPRs)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma_vc(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c) {  // d = a b + c
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
+}
+__device__ __forceinline__ void mfma_aa(f32x16& d, const bf16x8& a, const bf16x8& b) {  // d += a b   (d in AGPRs)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+}
+struct K3Item {  // wave-uniform description of one (batch-head, key block); pointers are rebuilt from it where needed (SGPR budget)
+    int b, hh, key0;  // key0: first key of this WAVE
+    bool valid;
+};
 
 __attribute__((amdgpu_waves_per_eu(1, 1)))
 __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) char sQO[P3_STAGES * P3_STAGE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
+    __shared__ __attribute__((aligned(16))) char sQO[P3_STAGES * P3_STAGE_BYTES + 4 * P3_R_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, lane_ = lane, h = lane >> 5, r32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nkt = (a.N + K3_KEYS - 1) / K3_KEYS;
+    const int nkt = (a.key_hi + K3_KEYS - 1) / K3_KEYS;  // key blocks of a (batch, head): keys [0, key_hi)
     const int BH = a.B * a.H;
-    int bh, kt;
-    if ((BH & 7) == 0) {
-        int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        bh = (slot / nkt) * 8 + xcd;
-        kt = slot % nkt;
-    } else {
-        bh = blockIdx.x / nkt;
-        kt = blockIdx.x % nkt;
-    }
-    const int b = bh / a.H, hh = bh % a.H;
     const int D = a.H * 64;
     const size_t rs = (size_t)3 * D;
-    const bf16_t* Qb = a.qkv + (size_t)b * a.N * rs + hh * 64;
-    const bf16_t* Kb = Qb + D;
-    const bf16_t* Vb = Qb + 2 * D;
-    const bf16_t* dOb = a.dO + (size_t)b * a.N * D + hh * 64;
-    const float* statb = a.delta + ((wave & 1) ? 0 : (size_t)a.B * a.H * a.N) + ((size_t)b * a.H + hh) * a.N;
     const int nt = (a.Nq + 63) / 64;
+    const int G = gridDim.x;
+    const bool xcd_map = (BH & 7) == 0 && (G & 7) == 0;
+    // k-th item of this workgroup.  XCD-aware: workgroups b and b + 8 share an XCD (and its L2): the items of one XCD are the key blocks of
+    // the (batch, head) pairs congruent to it, walked in order by its G / 8 workgroups, so that the key blocks of a pair run close in time.
+    auto item_of = [&](int k) {
+        K3Item it;
+        int bh, kt;
+        if (xcd_map) {
+            const int m = (int)(blockIdx.x >> 3) + k * (G >> 3);
+            it.valid = m < (BH >> 3) * nkt;
+            bh = (m / nkt) * 8 + (int)(blockIdx.x & 7);
+            kt = m % nkt;
+        } else {
+            const int m = (int)blockIdx.x + k * G;
+            it.valid = m < BH * nkt;
+            bh = m / nkt;
+            kt = m % nkt;
+        }
+        if (!it.valid) bh = kt = 0;
+        it.b = bh / a.H;
+        it.hh = bh % a.H;
+        it.key0 = kt * K3_KEYS + wave * 64;
+        return it;
+    };
+    auto q_base = [&](const K3Item& it) { return a.qkv + (size_t)it.b * a.N * rs + it.hh * 64; };  // q rows of the item's (batch, head); K at + D, V at + 2 D
 
     const int rowl = 16 * wave + (lane >> 3);
     const int lc8[2] = {((lane & 7) ^ swz64(rowl)) * 8, ((lane & 7) ^ swz64(rowl + 8)) * 8};
@@ -279,91 +104,85 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
     const unsigned smem0 = __builtin_amdgcn_readfirstlane(lds_addr(sQO));
     const unsigned smem_base = smem0 + 16 * wave * 128;
     const unsigned stat_dst = smem0 + 16384 + (wave & 1) * 256 + (wave >> 1) * 512;
-    auto issue = [&](int t, int slot) {
-        const unsigned sb = smem_base + slot * P3_STAGE_BYTES;
-        const bf16_t* qt = Qb + (size_t)t * 64 * rs;  // scalar bases
-        const bf16_t* ot = dOb + (size_t)t * 64 * D;
-        const float* st = statb + t * 64;
+    // The ring cursor: the next stage to issue is tile c_t of item c_it, at the running scalar pointers c_q / c_o / c_s; it runs P3_STAGES - 1
+    // stages ahead of the tile being computed, across item seams.  n_ahead = stages issued and not yet consumed.
+    int c_k = 0, c_t = 0, c_slot = 0, n_ahead = 0;
+    K3Item c_it = item_of(0);
+    const bf16_t* c_q;
+    const bf16_t* c_o;
+    const float* c_s;
+    auto cursor_ptrs = [&]() {
+        c_q = q_base(c_it);
+        c_o = a.dO + (size_t)c_it.b * a.N * D + c_it.hh * 64;
+        // waves 0/2 fetch the -LSE log2e rows, waves 1/3 the -delta rows; waves 2,3 write theirs to the scratch slot (uniform DMA count per wave)
+        c_s = a.delta + ((wave & 1) ? 0 : (size_t)a.B * a.H * a.N) + ((size_t)c_it.b * a.H + c_it.hh) * a.N;
+    };
+    cursor_ptrs();
+    auto advance = [&]() {
+        if (!c_it.valid) return;
+        const unsigned sb = smem_base + c_slot * P3_STAGE_BYTES;
         unsigned q0 = vq0, q1 = vq1, o0 = vo0, o1 = vo1, s0 = vs;
-        if (t * 64 + 64 > a.Nq) {  // partial tile: clamp query rows >= Nq to Nq-1 (valid data; their P is zeroed in the masked tile body)
-            const int r0 = min(t * 64 + rowl, a.Nq - 1) - t * 64, r1 = min(t * 64 + rowl + 8, a.Nq - 1) - t * 64;
+        if (c_t * 64 + 64 > a.Nq) {  // partial tile: clamp query rows >= Nq to Nq-1 (valid data; their P is zeroed in the masked tile body)
+            const int r0 = min(c_t * 64 + rowl, a.Nq - 1) - c_t * 64, r1 = min(c_t * 64 + rowl + 8, a.Nq - 1) - c_t * 64;
             q0 = (unsigned)(((size_t)r0 * rs + lc8[0]) * 2);
             q1 = (unsigned)(((size_t)r1 * rs + lc8[1]) * 2);
             o0 = (unsigned)(((size_t)r0 * D + lc8[0]) * 2);
             o1 = (unsigned)(((size_t)r1 * D + lc8[1]) * 2);
-            s0 = (unsigned)(min(t * 64 + lane, a.Nq - 1) - t * 64) * 4;
+            s0 = (unsigned)(min(c_t * 64 + lane, a.Nq - 1) - c_t * 64) * 4;
         }
-        glds16s(qt, q0, sb);
-        glds16s(ot, o0, sb + 8192);
-        glds16s(qt, q1, sb + 1024);
-        glds16s(ot, o1, sb + 8192 + 1024);
-        glds4s(st, s0, stat_dst + slot * P3_STAGE_BYTES);
+        glds16s(c_q, q0, sb);
+        glds16s(c_o, o0, sb + 8192);
+        glds16s(c_q, q1, sb + 1024);
+        glds16s(c_o, o1, sb + 8192 + 1024);
+        glds4s(c_s, s0, stat_dst + c_slot * P3_STAGE_BYTES);
+        c_slot = c_slot == P3_STAGES - 1 ? 0 : c_slot + 1;
+        ++n_ahead;
+        c_q += 64 * rs;
+        c_o += 64 * D;
+        c_s += 64;
+        if (++c_t == nt) {
+            c_t = 0;
+            c_it = item_of(++c_k);
+            cursor_ptrs();
+        }
     };
-    // top of tile t: stage t + 1 has landed (the step that reads it is two steps away), everyone is done with tile t - 1 -> its slot takes stage t + S - 1
 #ifdef DCV_K3_STAMP
-    unsigned long long st_wait = 0, st_issue = 0;
+    unsigned long long st_wait = 0, st_issue = 0, st_seam = 0, st_items = 0;
     const unsigned long long st_entry = K3_NOW();
 #endif
-    auto top = [&](int t, int slot) {
+    // top of tile t of the current item: stage t + 1 has landed (the step that reads it is two steps away), everyone is done with the previous
+    // tile -> its slot takes the cursor's stage.  Tiles 0 .. 2 of an item need no wait: their stages were issued before the item's seam, which
+    // drains (and the seam's K / V loads and dK / dV stores, younger than those stages, would make a counted wait over-wait).
+    auto top = [&](int t) {
 #ifdef DCV_K3_STAMP
-        const unsigned long long s0 = K3_NOW();
+        unsigned long long s0 = 0, s1 = 0, s2 = 0;
+        if (DCV_K3_STAMP >= 2) s0 = K3_NOW();
 #endif
-        const int rem = nt - 1 - t;
-        if (rem >= P3_STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P3_STAGES - 3) * P3_DMA) : "memory");
-        else if (rem == P3_STAGES - 3 && P3_STAGES >= 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P3_STAGES - 4) * P3_DMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        --n_ahead;  // the stage of this tile is being consumed
+        if (t >= 3) {
+            // stages younger than t + 1: n_ahead - 1
+            if (n_ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P3_DMA) : "memory");
+            else if (n_ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * P3_DMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
 #ifdef DCV_K3_STAMP
-        const unsigned long long s1 = K3_NOW();
+        if (DCV_K3_STAMP >= 2) s1 = K3_NOW();
 #endif
-        if (t + P3_STAGES - 1 < nt) issue(t + P3_STAGES - 1, slot == 0 ? P3_STAGES - 1 : slot - 1);
+        advance();
 #ifdef DCV_K3_STAMP
-        const unsigned long long s2 = K3_NOW();
-        st_wait += s1 - s0;
-        st_issue += s2 - s1;
+        if (DCV_K3_STAMP >= 2) {
+            s2 = K3_NOW();
+            st_wait += s1 - s0;
+            st_issue += s2 - s1;
+        }
 #endif
     };
 
-    const int key0 = kt * K3_KEYS + wave * 64;  // this wave's first key
-    const bool active = key0 < a.N;             // a wave without a single valid key only keeps the ring going
-    for (int st = 0; st < P3_STAGES - 1; ++st)
-        if (st < nt) issue(st, st);
-    if (!active) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int slot = 0;
-        for (int t = 0; t < nt; ++t) {
-            top(t, slot);
-            slot = slot == P3_STAGES - 1 ? 0 : slot + 1;
-        }
-        return;
-    }
-    bf16x8 kf[2][4], vf[2][4];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int kc = min(key0 + 32 * kb + r32, a.N - 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf[kb][ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Kb + (size_t)kc * rs + 16 * ks + 8 * h));
-            vf[kb][ks] = as_bf16x8(*reinterpret_cast<const uint4*>(Vb + (size_t)kc * rs + 16 * ks + 8 * h));
-        }
-    }
-    // hipcc's wait for these loads sits HERE: left to the first use it lands inside the tile loop, as s_waitcnt vmcnt(7 .. 0) in front of the first
-    // MFMAs of every tile — and vmcnt(0) there drains the LDS-DMA ring (measured: 75 cycles per MFMA instead of 35)
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"a"(kf[kb][ks]), "a"(vf[kb][ks]));
     const LaneOffs lo = lane_offs(lane);
-    f32x16 dk[2][2], dv[2][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            zero_acc(dk[kb][dt]);
-            zero_acc(dv[kb][dt]);
-        }
-
+    const int sto0 = 16384 + 16 * h;  // this lane-half's 4 consecutive query rows inside an 8-row group
+    bf16x8 kf[2][4], vf[2][4];   // K / V fragments of this wave's 64 keys (AGPRs)
+    f32x16 dk[2][2], dv[2][2];   // [key block][d half] (AGPRs)
     // register sets: X[0] = even units (kb 0), X[1] = odd units (kb 1)
     f32x16 sx[2], dpx[2];
     bf16x8 pf[2][2], dsf[2][2];  // [set][ss]
@@ -371,14 +190,55 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
     f32x16 stl, std_;            // -LSE log2e / -delta rows of the current slice, accumulator layout
     bf16x8 tr0[2][2][2];         // [slice parity][dt][dO | Q]: transposed fragments, k-step ss = 0
     bf16x8 tr1[2][2];            // the same for ss = 1 (one slice at a time)
+    // ---- region R of this wave
+    char* const sR = sQO + P3_STAGES * P3_STAGE_BYTES + wave * P3_R_BYTES;
+    const unsigned smemR = smem0 + P3_STAGES * P3_STAGE_BYTES + wave * P3_R_BYTES;
+    // piece j (0..7) of item it's K and V rows of this wave: keys key0 + 8j .. + 7 (clamped into the tensor), 128 B each, into rows 8j .. of the
+    // K tile and of the V tile; source chunks permuted as in a ring tile so that the fragment read below is lane_offs' row read
+    // (the lane-dependent address arithmetic of these two is rebuilt per call from an opaque copy of the lane number: hoisted out of the tile loop it
+    //  costs registers the loop does not have — and a spilled register's reload brings s_waitcnt vmcnt(0), which drains the ring)
+    auto kv_dma_pair = [&](const K3Item& it, int j) {
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        const int row = 8 * j + (lane >> 3);
+        const int key = min(it.key0 + row, a.N - 1);
+        const unsigned voff = (unsigned)(((size_t)key * rs + (((lane & 7) ^ swz64(row)) << 3)) * 2);
+        const bf16_t* kb_ = q_base(it) + D;
+        glds16s(kb_, voff, smemR + j * 1024);
+        glds16s(kb_ + D, voff, smemR + 8192 + j * 1024);
+    };
+    auto kv_frags = [&]() {  // R -> kf, vf (at the seam, behind the wave's own vmcnt(0): wave-private data, no barrier)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            pf[i][j] = dsf[i][j] = tr1[i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));
-            tr0[1][i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));
+            for (int ks = 0; ks < 4; ++ks) {
+                kf[kb][ks] = as_bf16x8(lds_read128(sR, lo.rows[ks] + kb * 4096));
+                vf[kb][ks] = as_bf16x8(lds_read128(sR, lo.rows[ks] + 8192 + kb * 4096));
+            }
+        // The fragments reach the accumulator file through v_accvgpr_write, which hipcc places where it likes — also directly in front of the asm
+        // MFMA that reads them, and it pads no hazard towards an asm statement (seen: key block 1 wrong on single-tile items).  This statement
+        // makes all sixteen registers "written" here, two wait states before anything can read them.
+        asm volatile("s_nop 1"
+                     : "+a"(kf[0][0]), "+a"(kf[0][1]), "+a"(kf[0][2]), "+a"(kf[0][3]), "+a"(kf[1][0]), "+a"(kf[1][1]), "+a"(kf[1][2]), "+a"(kf[1][3]),
+                       "+a"(vf[0][0]), "+a"(vf[0][1]), "+a"(vf[0][2]), "+a"(vf[0][3]), "+a"(vf[1][0]), "+a"(vf[1][1]), "+a"(vf[1][2]), "+a"(vf[1][3]));
+    };
+    // rows 8i .. 8i + 7 of the dK tile and of the dV tile in R -> HBM: 8 whole 128-byte rows per store instruction
+    auto store_pair = [&](const K3Item& it, int i) {
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+        const int row = 8 * i + (lane >> 3);
+        const int off = row * 128 + (((lane & 7) ^ swz64(row)) << 4);
+        const uint4 v0 = lds_read128(sR, off), v1 = lds_read128(sR, 8192 + off);
+#if defined(DCV_K3_ABL) && (DCV_K3_ABL & 1)  // timing-only ablation: no stores
+        asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w));
+#else
+        if (it.key0 + row < a.key_hi) {
+            bf16_t* const dst = a.dqkv + ((size_t)it.b * a.N + it.key0 + row) * rs + D + it.hh * 64 + (lane & 7) * 8;
+            *reinterpret_cast<uint4*>(dst) = v0;
+            *reinterpret_cast<uint4*>(dst + D) = v1;
         }
-    const int sto0 = 16384 + 16 * h;  // this lane-half's 4 consecutive query rows inside an 8-row group
+#endif
+    };
     auto load_rows = [&](int so, int qb, int i) {  // i = 0..15: one ds_read_b128 of the 16 that make (stl, std_, rq, rdo) of slice qb in stage so
         if (i < 4) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(sQO + so + sto0 + (32 * qb + 8 * i) * 4);
@@ -403,7 +263,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
     };
 
     // one step: J = position in the tile (unit (J >> 1, J & 1)); MASKED: rows >= Nq of this tile carry p = 0
-    auto step = [&](auto Jc, auto MASKED, int t, int so, int so_next) {
+    auto step = [&](auto Jc, auto MASKED, auto LAST, int t, int so, int so_next) {
         constexpr int J = decltype(Jc)::value;
         constexpr int X = J & 1, Y = X ^ 1;      // this unit's register set / the neighbours'
         constexpr int qb = J >> 1;               // this unit's slice
@@ -419,7 +279,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
             // ---- the MFMA of gap g
             if (g < 8) {
                 const int ks = g >> 1;
-                if ((g & 1) == 0) {
+                if constexpr (J == 3 && decltype(LAST)::value) {
+                    // no unit follows in this item
+                } else if ((g & 1) == 0) {
                     if (ks == 0) mfma_vc(sx[Y], rq[0], kf[Y][0], stl);
                     else mfma_vv(sx[Y], rq[ks], kf[Y][ks]);
                 } else {
@@ -470,7 +332,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
                 if (J == 0) {
                     load_rows(so, 1, i);
                     load_rows(so, 1, i + 1);
-                } else {
+                } else if constexpr (!decltype(LAST)::value) {
                     load_rows(so_next, 0, i);
                     load_rows(so_next, 0, i + 1);
                 }
@@ -489,87 +351,148 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
     using J1 = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>;
     using J3 = std::integral_constant<int, 3>;
-
-    // prologue: stage 0, the rows of slice (0, 0), S' and dP' of unit 0
-    {
-        const int inflight = min(nt, P3_STAGES - 1) - 1;  // stages younger than stage 0
-        if (inflight >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * P3_DMA) : "memory");
-        else if (inflight == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P3_DMA) : "memory");
-        else if (inflight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * P3_DMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+    // dK (x 1 / log2 e: q arrived pre-scaled by scale log2 e) and dV of this wave's 64 keys: accumulators -> bf16 -> R (row = key, 16-byte chunks
+    // permuted by swz64(row): the 8-byte writes of 16 lanes fall into 16 different bank pairs)
+    auto acc_to_R = [&]() {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) load_rows(0, 0, i);
-        P3_FENCE();
+        for (int which = 0; which < 2; ++which) {
+            const float mul = which == 0 ? 1.f / LOG2E : 1.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks == 0) {
-                mfma_vc(sx[0], rq[0], kf[0][0], stl);
-                mfma_vc(dpx[0], rdo[0], vf[0][0], std_);
-            } else {
-                mfma_vv(sx[0], rq[ks], kf[0][ks]);
-                mfma_vv(dpx[0], rdo[ks], vf[0][ks]);
-            }
-        }
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        P3_FENCE();
-    }
-    auto tile = [&](auto MASKED, int t, int slot) {
-        top(t, slot);
-        const int so = slot * P3_STAGE_BYTES;
-        const int so_next = (slot == P3_STAGES - 1 ? 0 : slot + 1) * P3_STAGE_BYTES;
-        P3_FENCE();
-        step(J0{}, MASKED, t, so, so_next);
-        step(J1{}, MASKED, t, so, so_next);
-        step(J2{}, MASKED, t, so, so_next);
-        step(J3{}, MASKED, t, so, so_next);
-    };
-    const int nfull = a.Nq / 64;
-    int slot = 0;
-#ifdef DCV_K3_STAMP
-    const unsigned long long st_loop0 = K3_NOW();
-#endif
-    for (int t = 0; t < nfull; ++t) {
-        tile(No{}, t, slot);
-        slot = slot == P3_STAGES - 1 ? 0 : slot + 1;
-    }
-    if (nfull < nt) tile(Yes{}, nfull, slot);
-#ifdef DCV_K3_STAMP
-    const unsigned long long st_loop1 = K3_NOW();
-#endif
-    // epilogue: dV^T / dK^T of the last unit (set 1, slice parity 1)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int ss = i >> 2, dt = (i >> 1) & 1;
-        const bf16x8& aT = ss == 0 ? tr0[1][dt][i & 1] : tr1[dt][i & 1];
-        if ((i & 1) == 0) mfma_aa(dv[1][dt], aT, pf[1][ss]);
-        else mfma_aa(dk[1][dt], aT, dsf[1][ss]);
-    }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    P3_FENCE();
-
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x16& acc = which == 0 ? dk[kb][dt] : dv[kb][dt];
+                    const int row = 32 * kb + r32;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-        const int key = key0 + 32 * kb + r32;
-        if (key < a.N) {
-            bf16_t* dkp = a.dqkv + ((size_t)b * a.N + key) * rs + D + hh * 64;
-            bf16_t* dvp = dkp + D;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float ks_ = 1.f / LOG2E;
-                    uint2 v1 = pack4_bf16(dk[kb][dt][4 * g] * ks_, dk[kb][dt][4 * g + 1] * ks_, dk[kb][dt][4 * g + 2] * ks_, dk[kb][dt][4 * g + 3] * ks_);
-                    uint2 v2 = pack4_bf16(dv[kb][dt][4 * g], dv[kb][dt][4 * g + 1], dv[kb][dt][4 * g + 2], dv[kb][dt][4 * g + 3]);
-                    *reinterpret_cast<uint2*>(dkp + 32 * dt + 8 * g + 4 * h) = v1;
-                    *reinterpret_cast<uint2*>(dvp + 32 * dt + 8 * g + 4 * h) = v2;
+                    for (int g = 0; g < 4; ++g) {
+                        const uint2 v = make_uint2(pack2_bf16(acc[4 * g] * mul, acc[4 * g + 1] * mul), pack2_bf16(acc[4 * g + 2] * mul, acc[4 * g + 3] * mul));
+                        *reinterpret_cast<uint2*>(sR + which * 8192 + row * 128 + (((4 * dt + g) ^ swz64(row)) << 4) + 8 * h) = v;
+                    }
                 }
         }
+    };
+    // HBM traffic of the neighbouring items, a few pieces per tile (in_loop), or all of it at the seam when an item is too short for that
+    const bool in_loop = nt >= 16;
+    K3Item prev, nxt;
+    bool prev_active = false, nxt_active = false;
+    auto trickle = [&](int t) {
+        if (!in_loop) return;
+        if (prev_active && t < 8) store_pair(prev, t);
+        if (nxt_active && t >= nt - 12 && t < nt - 4) kv_dma_pair(nxt, t - (nt - 12));
+    };
+
+    int slot = 0;  // ring slot of the tile being computed
+    // LAST: the last tile of an item — always the masked body (a full last tile masks nothing) — skips S' / dP' of the unit after it (the next
+    // item's first unit is computed in that item's prologue, with ITS K / V fragments)
+    auto tile = [&](auto LAST, int t) {
+        top(t);
+        trickle(t);
+        const int so = slot * P3_STAGE_BYTES;
+        slot = slot == P3_STAGES - 1 ? 0 : slot + 1;
+        const int so_next = slot * P3_STAGE_BYTES;
+        P3_FENCE();
+        step(J0{}, LAST, LAST, t, so, so_next);
+        step(J1{}, LAST, LAST, t, so, so_next);
+        step(J2{}, LAST, LAST, t, so, so_next);
+        step(J3{}, LAST, LAST, t, so, so_next);
+    };
+
+    for (int st = 0; st < P3_STAGES - 1; ++st) advance();
+    K3Item cur = item_of(0);
+    prev = cur;
+    if (cur.valid && cur.key0 < a.key_hi)
+        for (int j = 0; j < 8; ++j) kv_dma_pair(cur, j);
+    for (int k = 0; cur.valid; ++k) {
+#ifdef DCV_K3_STAMP
+        const unsigned long long q0 = K3_NOW();
+#endif
+        const bool active = cur.key0 < a.key_hi;  // a wave without a single valid key only keeps the ring going
+        nxt = item_of(k + 1);
+        nxt_active = nxt.valid && nxt.key0 < a.key_hi;
+        // ---- seam: everything this wave has in flight has landed (its pieces of the stages issued so far, this item's K / V rows in R, the
+        // previous item's stores); after the barrier the stages have landed for every wave, and everyone is done with the previous item's last tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (active) kv_frags();
+        if (prev_active) acc_to_R();  // behind the fragment reads: one wave's LDS operations execute in order
+        if (!in_loop) {
+            if (prev_active)
+                for (int i = 0; i < 8; ++i) store_pair(prev, i);
+            if (nxt_active)
+                for (int j = 0; j < 8; ++j) kv_dma_pair(nxt, j);
+        }
+        if (active) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    zero_acc(dk[kb][dt]);
+                    zero_acc(dv[kb][dt]);
+                }
+            asm volatile("s_nop 1"  // as in kv_frags: the v_accvgpr_writes of the zeroing sit above this statement, not in front of an asm MFMA
+                         : "+a"(dk[0][0]), "+a"(dk[0][1]), "+a"(dk[1][0]), "+a"(dk[1][1]), "+a"(dv[0][0]), "+a"(dv[0][1]), "+a"(dv[1][0]), "+a"(dv[1][1]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    pf[i][j] = dsf[i][j] = tr1[i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));  // the first step's dV / dK MFMAs (unit -1) add zero
+                    tr0[1][i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));
+                }
+            // prologue: the rows of slice (0, 0), S' and dP' of unit 0
+            const int so = slot * P3_STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) load_rows(so, 0, i);
+            P3_FENCE();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks == 0) {
+                    mfma_vc(sx[0], rq[0], kf[0][0], stl);
+                    mfma_vc(dpx[0], rdo[0], vf[0][0], std_);
+                } else {
+                    mfma_vv(sx[0], rq[ks], kf[0][ks]);
+                    mfma_vv(dpx[0], rdo[ks], vf[0][ks]);
+                }
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            P3_FENCE();
+        }
+#ifdef DCV_K3_STAMP
+        const unsigned long long q1 = K3_NOW();
+        st_seam += q1 - q0;
+        ++st_items;
+#endif
+        if (active) {
+            for (int t = 0; t < nt - 1; ++t) tile(No{}, t);
+            tile(Yes{}, nt - 1);
+            // dV^T / dK^T of the last unit (set 1, slice parity 1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ss = i >> 2, dt = (i >> 1) & 1;
+                const bf16x8& aT = ss == 0 ? tr0[1][dt][i & 1] : tr1[dt][i & 1];
+                if ((i & 1) == 0) mfma_aa(dv[1][dt], aT, pf[1][ss]);
+                else mfma_aa(dk[1][dt], aT, dsf[1][ss]);
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            P3_FENCE();
+        } else {
+            for (int t = 0; t < nt; ++t) {
+                top(t);
+                trickle(t);
+                slot = slot == P3_STAGES - 1 ? 0 : slot + 1;
+            }
+        }
+        prev = cur;
+        prev_active = active;
+        cur = nxt;
+    }
+    if (prev_active) {  // the last item's outputs
+        acc_to_R();
+        for (int i = 0; i < 8; ++i) store_pair(prev, i);
     }
 #ifdef DCV_K3_STAMP
-    if (tid == 0 && blockIdx.x < 8192) {
+    if (tid == 0 && blockIdx.x < 1024) {
         unsigned long long* o = k3_stamps + (size_t)blockIdx.x * 8;
-        o[0] = st_entry; o[1] = st_loop0; o[2] = st_loop1; o[3] = K3_NOW(); o[4] = st_wait; o[5] = st_issue; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = nt;
+        o[0] = st_entry; o[1] = st_seam; o[2] = st_items; o[3] = K3_NOW(); o[4] = st_wait; o[5] = st_issue; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = nt;
     }
 #endif
 }
@@ -581,16 +504,30 @@ extern "C" int dcv_k3_stamps(void* host_dst, size_t bytes) {
 }
 #endif
 
-extern "C" int dcv_attn_bwd_dkdv_rows_ps3(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
-                                          int H, int head_dim, float scale, void* stream) {
-    int rc = attn_check(qkv, B, N, H, head_dim);
-    if (rc) return rc;
-    if (!dO || !lse || !ws || !dqkv) return DCV_ERR_NULL;
-    if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
+static int k3_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+// dK / dV of all keys.  The persistent kernel takes the key blocks of 256; a remainder of at most 128 keys per (batch, head) (N = 1569: 33) would
+// cost it a whole item time per pair with one wave of four at work and leave the workgroups unevenly loaded (10.5 items each): that remainder
+// goes to the second form (attn_bwd.hip, 128 keys per workgroup), launched behind it on the same stream for exactly those keys.
+int dcv_dkdv3_launch(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq, int H, float scale,
+                     hipStream_t stream) {
     AttnArgs a{(const bf16_t*)qkv, nullptr, (const bf16_t*)dO, (float*)lse, (float*)ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
-    const dim3 grid(B * H * ((N + K3_KEYS - 1) / K3_KEYS));
-    if (DCV_K3_PIPE) hipLaunchKernelGGL(attn_bwd_dkdv3p_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(attn_bwd_dkdv3_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
-    DCV_LAUNCH_CHECK();
+    const int rem = N % K3_KEYS;
+    const bool split = rem != 0 && rem <= 128 && N > K3_KEYS;
+    a.key_lo = 0;
+    a.key_hi = split ? N - rem : N;
+    const long items = (long)B * H * ((a.key_hi + K3_KEYS - 1) / K3_KEYS);
+    const int cus = k3_cus();  // one workgroup per CU (149 KB of LDS, > 256 registers per lane)
+    hipLaunchKernelGGL(attn_bwd_dkdv3p_kernel, dim3((unsigned)(items < cus ? items : cus)), dim3(256), 0, stream, a);
+    if (hipGetLastError() != hipSuccess) return DCV_ERR_LAUNCH;
+    if (split) return dcv_dkdv2_range(qkv, dO, lse, ws, dqkv, B, N, Nq, H, scale, N - rem, stream);
     return DCV_OK;
 }

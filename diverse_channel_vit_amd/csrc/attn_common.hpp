@@ -32,6 +32,7 @@ struct AttnArgs {
     int B, N, H;
     float scale;
     int Nq;  // query rows [0, Nq) of every (batch, head) are processed (Nq = N: all; Nq = 1: the CLS row of the last block)
+    int key_lo = 0, key_hi = 0;  // dK / dV kernels launched for a key range only: keys [key_lo, key_hi) (0, 0: all)
 };
 
 // stage a [64 rows][64 cols] bf16 tile: 512 chunks of 16 B, 256 threads x 2
@@ -126,3 +127,13 @@ inline int attn_check(const void* qkv, int B, int N, int H, int hd) {
 }
 
 }  // namespace
+
+// attn_bwd.hip: the second dK / dV form (pre-scaled q) for keys [key_lo, N) only; key_lo a multiple of 128
+__attribute__((visibility("hidden"))) int dcv_dkdv2_range(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq, int H, float scale, int key_lo,
+                    hipStream_t stream);
+// attn_bwd3.hip: the third dK / dV form (pre-scaled q): persistent, one wave per SIMD; all keys (the remainder of < 129 keys through dcv_dkdv2_range)
+__attribute__((visibility("hidden"))) int dcv_dkdv3_launch(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
+                                                           int H, float scale, hipStream_t stream);
+#ifndef DCV_DKDV_FORM
+#define DCV_DKDV_FORM 3  // 2: dcv_attn_bwd_dkdv_rows_ps keeps the second form (A/B builds)
+#endif

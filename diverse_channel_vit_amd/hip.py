@@ -387,7 +387,8 @@ def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None, presc
     with _timer(lambda: ("attn_bwd_dq2_kernel" + tp, f"B{B} N{N} H{H} Nq{nq}", 1 * prod, 3 * prod, 2.0 * B * (N * 3 * D_ + nq * 3 * D_))):  # also writes the row statistics
         rc = dq_fn(_p(qkv), _p(o), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dq")
-    with _timer(lambda: ("attn_bwd_dkdv2_kernel" + tp, f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 1 * D_ + N * 2 * D_))):
+    # pre-scaled q: the persistent third form (csrc/attn_bwd3.hip) + the second form's launch for a key remainder < 129; plain: the second form
+    with _timer(lambda: (("attn_bwd_dkdv3p_kernel" if prescaled else "attn_bwd_dkdv2_kernel<false>"), f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 1 * D_ + N * 2 * D_))):
         rc = dkdv_fn(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dkdv")
 

@@ -1,5 +1,5 @@
-"""Round-5 harness for the third dK/dV kernel (csrc/attn_bwd3.hip): bitwise comparison with the second form (attn_bwd.hip, same summation order) on
-several shapes, then interleaved timing at the headline shape.  python tools/attn3_check.py [lib.so ...]"""
+"""Round-5 harness for the third dK/dV kernel (csrc/attn_bwd3.hip): bitwise comparison with the second form (attn_bwd.hip, same summation order; a
+-DDCV_DKDV_FORM=2 build, libdcv_hip_dkdv2.so) on several shapes, then interleaved timing at the headline shape.  python tools/attn3_check.py [lib.so ...]"""
 import ctypes as C
 import os
 import sys
@@ -44,13 +44,14 @@ def run(h, name, d, nq):
 
 
 h0 = hs[0]
+href = C.CDLL(os.path.join(ROOT, "diverse_channel_vit_amd", "libdcv_hip_dkdv2.so"))  # -DDCV_DKDV_FORM=2 build: the second form behind the same entry
 ok = True
 for (B, N, H, nq) in [(1, 64, 1, 64), (2, 256, 2, 256), (1, 77, 3, 77), (2, 320, 6, 320), (3, 1569, 6, 1569), (2, 1569, 6, 1), (2, 600, 6, 33), (1, 4100, 2, 4100)]:
     d = make(B, N, H, seed=N)
     prep(h0, d, nq)
-    ref = run(h0, "dcv_attn_bwd_dkdv_rows_ps", d, nq)
+    ref = run(href, "dcv_attn_bwd_dkdv_rows_ps", d, nq)
     for h, l in zip(hs, libs):
-        new = run(h, "dcv_attn_bwd_dkdv_rows_ps3", d, nq)
+        new = run(h, "dcv_attn_bwd_dkdv_rows_ps", d, nq)
         D = 64 * H
         a, b_ = ref[:, :, D:].float(), new[:, :, D:].float()
         bad = int((torch.isnan(b_) | (a != b_)).sum())
@@ -65,7 +66,7 @@ if os.environ.get("A3_TIME", "1") != "0":
             d = make(64, N, 6, zero=zero)
             prep(h0, d, N)
             out = torch.empty_like(d["qkv"])
-            names = [(h0, "dcv_attn_bwd_dkdv_rows_ps", "dkdv2")] + [(h, "dcv_attn_bwd_dkdv_rows_ps3", "dkdv3:" + os.path.basename(l)) for h, l in zip(hs, libs)]
+            names = [(href, "dcv_attn_bwd_dkdv_rows_ps", "dkdv2")] + [(h, "dcv_attn_bwd_dkdv_rows_ps", "dkdv3:" + os.path.basename(l)) for h, l in zip(hs, libs)]
             res = {n[2]: [] for n in names}
             for rnd in range(14):
                 for h, fn, tag in names:
