@@ -29,6 +29,9 @@
 
 namespace {
 
+#ifndef DCV_K3_ABL
+#define DCV_K3_ABL 0  // timing-only ablations (tools/attn3_fit.py on variant builds): 1 no stores, 2 no K/V DMA, 4 no ring DMA inside items, 8 no wait / barrier per tile,
+#endif                 // 16 no vector fillers, 32 no LDS fragment reads in the steps, 64 no MFMAs
 constexpr int K3_KEYS = 256;  // keys per workgroup item
 constexpr int P3_STAGES = 5, P3_STAGE_BYTES = 16384 + 1024, P3_DMA = 5;  // stage: Q tile | dO tile | -LSE log2e [64] | -delta [64] | 512 B scratch
 constexpr int P3_R_BYTES = 16384;  // per-wave region R: next item's K tile | V tile (swizzled like a ring tile), then this item's dK | dV tiles
@@ -38,6 +41,13 @@ __device__ unsigned long long k3_stamps[1024 * 8];
 #define K3_NOW() __builtin_amdgcn_s_memtime()
 #endif
 #define P3_FENCE() __builtin_amdgcn_sched_barrier(0)
+// even step, gap g: which of the 16 row / statistics reads (load_rows index: 0-3 stl, 4-7 std_, 8-11 rq, 12-15 rdo) and which of the 8 transposed
+// reads go out.  A register is reloaded only after the MFMA that last read it: stl / std_ (C operands of MFMA 0 / 1) from gap 2, rq[ks] after
+// MFMA 2 ks, rdo[ks] after MFMA 2 ks + 1.
+constexpr int P3_ROWS_AT[16][2] = {{-1, -1}, {-1, -1}, {0, 1}, {2, 3}, {4, 5}, {6, 7}, {8, 9}, {12, 13}, {10, 14}, {11, -1}, {15, -1},
+                                   {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
+constexpr int P3_TR0_AT[16][2] = {{0, -1}, {1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1},
+                                  {2, -1}, {3, -1}, {4, -1}, {5, -1}, {6, 7}};
 #define P3_PIN(x) asm volatile("" : "+v"(x))
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {  // one v_cvt_pk_bf16_f32
@@ -130,11 +140,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
             o1 = (unsigned)(((size_t)r1 * D + lc8[1]) * 2);
             s0 = (unsigned)(min(c_t * 64 + lane, a.Nq - 1) - c_t * 64) * 4;
         }
-        glds16s(c_q, q0, sb);
-        glds16s(c_o, o0, sb + 8192);
-        glds16s(c_q, q1, sb + 1024);
-        glds16s(c_o, o1, sb + 8192 + 1024);
-        glds4s(c_s, s0, stat_dst + c_slot * P3_STAGE_BYTES);
+        {  // the five pieces of this wave in one statement: M0 (the LDS destination) saved and restored once
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %9\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, %6\n\t"
+                "s_add_u32 m0, %9, 0x2000\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %2, %7\n\t"
+                "s_add_u32 m0, %9, 0x400\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %3, %6\n\t"
+                "s_add_u32 m0, %9, 0x2400\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %4, %7\n\t"
+                "s_mov_b32 m0, %10\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dword %5, %8\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(q0), "v"(o0), "v"(q1), "v"(o1), "v"(s0), "s"(c_q), "s"(c_o), "s"(c_s), "s"(sb), "s"(stat_dst + c_slot * P3_STAGE_BYTES)
+                : "memory", "scc");
+        }
         c_slot = c_slot == P3_STAGES - 1 ? 0 : c_slot + 1;
         ++n_ahead;
         c_q += 64 * rs;
@@ -150,26 +179,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
     unsigned long long st_wait = 0, st_issue = 0, st_seam = 0, st_items = 0;
     const unsigned long long st_entry = K3_NOW();
 #endif
-    // top of tile t of the current item: stage t + 1 has landed (the step that reads it is two steps away), everyone is done with the previous
-    // tile -> its slot takes the cursor's stage.  Tiles 0 .. 2 of an item need no wait: their stages were issued before the item's seam, which
-    // drains (and the seam's K / V loads and dK / dV stores, younger than those stages, would make a counted wait over-wait).
+    // Every second tile (even t): everything this wave has in flight has landed — the stages issued two tiles ago (t + 1, t + 2: tile t + 1 reads the rows of
+    // t + 2), the trickled pieces — then, behind the barrier, everyone is done with the tiles before t and the ring is refilled up to stage
+    // t + 4.  One barrier and one scalar prologue per TWO tiles: at one per tile they cost 470 cycles of a 2800-cycle tile (timing-only ablation).
     auto top = [&](int t) {
 #ifdef DCV_K3_STAMP
         unsigned long long s0 = 0, s1 = 0, s2 = 0;
         if (DCV_K3_STAMP >= 2) s0 = K3_NOW();
 #endif
-        --n_ahead;  // the stage of this tile is being consumed
-        if (t >= 3) {
-            // stages younger than t + 1: n_ahead - 1
-            if (n_ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P3_DMA) : "memory");
-            else if (n_ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * P3_DMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(DCV_K3_ABL & 8)) {
+            if (t != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // t = 0: the item's seam has drained
+            __builtin_amdgcn_s_barrier();
         }
-        __builtin_amdgcn_s_barrier();
 #ifdef DCV_K3_STAMP
         if (DCV_K3_STAMP >= 2) s1 = K3_NOW();
 #endif
-        advance();
+        if (!(DCV_K3_ABL & 4))
+            while (n_ahead < P3_STAGES && c_it.valid) advance();
 #ifdef DCV_K3_STAMP
         if (DCV_K3_STAMP >= 2) {
             s2 = K3_NOW();
@@ -204,6 +230,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
         const int key = min(it.key0 + row, a.N - 1);
         const unsigned voff = (unsigned)(((size_t)key * rs + (((lane & 7) ^ swz64(row)) << 3)) * 2);
         const bf16_t* kb_ = q_base(it) + D;
+        if (DCV_K3_ABL & 2) return;
         glds16s(kb_, voff, smemR + j * 1024);
         glds16s(kb_ + D, voff, smemR + 8192 + j * 1024);
     };
@@ -229,7 +256,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
         const int row = 8 * i + (lane >> 3);
         const int off = row * 128 + (((lane & 7) ^ swz64(row)) << 4);
         const uint4 v0 = lds_read128(sR, off), v1 = lds_read128(sR, 8192 + off);
-#if defined(DCV_K3_ABL) && (DCV_K3_ABL & 1)  // timing-only ablation: no stores
+#if (DCV_K3_ABL & 1)  // timing-only ablation: no stores
         asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w));
 #else
         if (it.key0 + row < a.key_hi) {
@@ -267,17 +294,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
         constexpr int J = decltype(Jc)::value;
         constexpr int X = J & 1, Y = X ^ 1;      // this unit's register set / the neighbours'
         constexpr int qb = J >> 1;               // this unit's slice
-        constexpr int qbn = ((J + 1) >> 1) & 1;  // slice of unit u + 1 (rows already in rq / rdo)
         constexpr int qbp = ((J + 3) >> 1) & 1;  // slice of unit u - 1
         const bf16x8 pfy[2] = {pf[Y][0], pf[Y][1]}, dsfy[2] = {dsf[Y][0], dsf[Y][1]};
         const int lim = a.Nq - t * 64 - 32 * qb - 4 * h;  // MASKED: accumulator row index (r & 3) + 8 (r >> 2) >= lim does not exist
         bf16x4 half[2];
         float pv[16], dsv[16];
         unsigned pw[8], dw[8];  // packed P / dS pairs: word i of k-step ss = i >> 2
+        if (DCV_K3_ABL & 16)
+            for (int i = 0; i < 8; ++i) pw[i] = dw[i] = 0;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             // ---- the MFMA of gap g
-            if (g < 8) {
+            if (DCV_K3_ABL & 64) {
+            } else if (g < 8) {
                 const int ks = g >> 1;
                 if constexpr (J == 3 && decltype(LAST)::value) {
                     // no unit follows in this item
@@ -296,6 +325,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
             }
             // ---- fillers: the vector work of this unit, one element per gap; the multiply and the packing trail the exponential by one and two
             // gaps (a dependent instruction right behind a v_exp waits for its result: nothing else is there to issue with one wave per SIMD)
+            if (!(DCV_K3_ABL & 16)) {
             float p = __builtin_amdgcn_exp2f(sx[X][g]);
             if constexpr (decltype(MASKED)::value) {
                 if ((g & 3) + 8 * (g >> 2) >= lim) p = 0.f;
@@ -323,19 +353,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
                 P3_PIN(dw[6]);
                 P3_PIN(dw[7]);
             }
-            // ---- ... and the LDS reads of the steps ahead
-            if (g < 8) {
-                if ((J & 1) == 0) load_tr(tr0[qb], so, qb, 0, g, half);  // even step: k-step 0 of this slice's transposed fragments (first used next step)
-                else load_tr(tr1, so, qb, 1, g, half);                   // odd step: k-step 1 (used from MFMA 12 of this step)
-            } else if ((J & 1) == 0) {                                   // even step, after the last MFMA that read rq / rdo / stl / std_: the next slice's
-                const int i = 2 * (g - 8);
-                if (J == 0) {
-                    load_rows(so, 1, i);
-                    load_rows(so, 1, i + 1);
-                } else if constexpr (!decltype(LAST)::value) {
-                    load_rows(so_next, 0, i);
-                    load_rows(so_next, 0, i + 1);
+            }
+            // ---- ... and the LDS reads of the steps ahead.  Even step: the next slice's rows and statistics go out as soon as the MFMA that last read
+            // each register has issued (tables below) — 13 and more gaps before their first use, so the burst of the four lockstepped waves
+            // (64 ds_read_b128 within ~300 cycles: the LDS array is busy for 256 of them) queues without anybody waiting for it — and k-step 0 of this
+            // slice's transposed fragments (first used in the next step's second half) fills the rest.  Odd step: k-step 1 (used from MFMA 12 on).
+            if (DCV_K3_ABL & 32) {
+            } else if ((J & 1) == 0) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int i = P3_ROWS_AT[g][e];
+                    if (i >= 0) {
+                        if (J == 0) load_rows(so, 1, i);
+                        else if constexpr (!decltype(LAST)::value) load_rows(so_next, 0, i);
+                    }
+                    const int j = P3_TR0_AT[g][e];
+                    if (j >= 0) load_tr(tr0[qb], so, qb, 0, j, half);
                 }
+            } else if (g < 8) {
+                load_tr(tr1, so, qb, 1, g, half);
             }
             P3_FENCE();
         }
@@ -372,21 +408,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
         }
     };
     // HBM traffic of the neighbouring items, a few pieces per tile (in_loop), or all of it at the seam when an item is too short for that
-    const bool in_loop = nt >= 16;
+    const bool in_loop = nt >= 16;  // 8 tiles of stores, then 8 tiles of K / V rows ending 2-4 tiles before the seam
     K3Item prev, nxt;
     bool prev_active = false, nxt_active = false;
-    auto trickle = [&](int t) {
+    const int kv_t0 = (nt - 12) & ~1;  // first tile of the K / V window
+    auto trickle = [&](int t) {  // at even tiles, behind top(): two pairs each, two tiles in flight before the next top waits for them
         if (!in_loop) return;
-        if (prev_active && t < 8) store_pair(prev, t);
-        if (nxt_active && t >= nt - 12 && t < nt - 4) kv_dma_pair(nxt, t - (nt - 12));
+        if (prev_active && t < 8) {
+            store_pair(prev, t);
+            store_pair(prev, t + 1);
+        }
+        if (nxt_active && t >= kv_t0 && t < kv_t0 + 8) {
+            kv_dma_pair(nxt, t - kv_t0);
+            kv_dma_pair(nxt, t - kv_t0 + 1);
+        }
     };
 
     int slot = 0;  // ring slot of the tile being computed
     // LAST: the last tile of an item — always the masked body (a full last tile masks nothing) — skips S' / dP' of the unit after it (the next
     // item's first unit is computed in that item's prologue, with ITS K / V fragments)
     auto tile = [&](auto LAST, int t) {
-        top(t);
-        trickle(t);
+        if ((t & 1) == 0) {
+            top(t);
+            trickle(t);
+        }
+        --n_ahead;  // this tile's stage is being consumed
         const int so = slot * P3_STAGE_BYTES;
         slot = slot == P3_STAGES - 1 ? 0 : slot + 1;
         const int so_next = slot * P3_STAGE_BYTES;
@@ -476,8 +522,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
             P3_FENCE();
         } else {
             for (int t = 0; t < nt; ++t) {
-                top(t);
-                trickle(t);
+                if ((t & 1) == 0) {
+                    top(t);
+                    trickle(t);
+                }
+                --n_ahead;
                 slot = slot == P3_STAGES - 1 ? 0 : slot + 1;
             }
         }
