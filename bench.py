@@ -551,8 +551,17 @@ def main():
             limit = float(wd_env) if wd_env else max(180.0, 30.0 * best[1][0])
 
             def bail(limit=limit):
+                # a firing watchdog is a FINDING, not a success: the line carries a top-level status and what the reducer was waiting for
+                # (ADVICE r4); the exit code stays 0 so that the driver still records the valid single-all-reduce measurement
+                pending = None
+                try:
+                    pending = dp.pending_state()
+                except Exception as e:  # the reducer may be mid-update in the main thread
+                    pending = f"unavailable: {e!r}"
                 if rank == 0 and fallback is not None:
-                    fallback["dp"]["modes"]["overlap"] = {"status": f"did not finish within {limit:.0f} s: the line reports the single all-reduce mode"}
+                    fallback["status"] = "overlap_hang"
+                    fallback["dp"]["modes"]["overlap"] = {"status": f"did not finish within {limit:.0f} s: the line reports the single all-reduce mode",
+                                                          "pending": pending}
                     fallback["dp"]["rccl_channels_in_use"] = dcv.DataParallel.rccl_channels_from_log(rccl_log) if rccl_log else None
                     print(json.dumps(fallback), flush=True)
                 os._exit(0)
@@ -577,6 +586,7 @@ def main():
     chosen_mode, (dt, med_ms, live, loss) = best
     final_loss = loss.item()
     line = build_line(dt, med_ms, live, final_loss, chosen_mode)
+    line["status"] = "ok"
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,8 +16,8 @@ EXTRA = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
          # backward: additionally no SLP vectorizer — its v_pk_* packing of the dS arithmetic costs 48 register-pair moves per tile
          # (dK/dV kernel 4 % slower); the forward keeps it (its packed forms are written out and measured 2 % faster)
          "attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
-         "attn_bwd3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
-         "attn_bwd_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
+         # third dK/dV form: its MFMAs are inline asm with explicit register classes; the flag keeps hipcc's own choices out of the accumulator file
+         "attn_bwd3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
 
 
 def sources():

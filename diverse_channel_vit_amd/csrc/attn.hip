@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
             // first tile: the reference becomes the tile's maximum whatever its sign (the accumulators started at 0); later tiles: lazily, as below
             if (t == 0 || __any(mx > FWD_RESCALE_LOG2)) {
                 const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(-d);
+                // t = 0: l and O are still zero, and exp2(-d) is +inf when every score of the first tile lies below -127 (log2 units): 0 * inf = NaN
+                const float alpha = (t == 0) ? 0.f : __builtin_amdgcn_exp2f(-d);
                 l *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)

@@ -553,6 +553,20 @@ __device__ __forceinline__ void np_issue(const NpTile& t, int kt, unsigned stage
     for (int q = 0; q < 4; ++q) glds16(t.gW[q] + kt * NP_BK, stage_base + dmaW + q * 1024);
 }
 
+// Round 5: the two co-resident workgroups of a CU start at the same instant on identical work, so both sit in the k-loop, then
+// both in the epilogue: no overlap by construction.  -DDCV_PAIR_OFFSET=<cycles> (variant builds; 0 in the product) delays, once, the workgroup
+// whose waves got the SECOND wave slot of their SIMD (HW_ID.wave_id != 0) before its first stage; -DDCV_PAIR_STAMP records the cycle at which each
+// of a workgroup's first 24 epilogues starts, with the CU it runs on (tools/gemm_pair_phase.py checks that the pair stays out of phase).
+#ifndef DCV_PAIR_OFFSET
+#define DCV_PAIR_OFFSET 0
+#endif
+#ifdef DCV_PAIR_STAMP
+__device__ unsigned long long np_stamps[1024 * 32];
+extern "C" int dcv_pair_stamps(void* host_dst, size_t bytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(np_stamps), bytes < sizeof(np_stamps) ? bytes : sizeof(np_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_pair_kernel(GemmNtArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[NP_SMEM];
@@ -580,6 +594,21 @@ __global__ __launch_bounds__(256) void gemm_nt_pair_kernel(GemmNtArgs a) {
     NpTile cur, nxt;
     np_tile_setup(a, L, tiles_n, wave, lane, cur);
     int g = 0;  // global stage counter: stage g lives in buffer g & 1
+#if DCV_PAIR_OFFSET || defined(DCV_PAIR_STAMP)
+    const unsigned hw_id = __builtin_amdgcn_s_getreg((15 << 11) | 4);       // HW_REG_HW_ID[15:0]: wave_id 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+    const unsigned xcc_id = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15;  // HW_REG_XCC_ID[3:0]
+    const bool second = (hw_id & 15) != 0;
+#endif
+#if DCV_PAIR_OFFSET
+    if (second) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)DCV_PAIR_OFFSET) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
+#ifdef DCV_PAIR_STAMP
+    int n_epi = 0;
+    if (tid == 0 && blockIdx.x < 1024) np_stamps[blockIdx.x * 32] = ((unsigned long long)xcc_id << 32) | hw_id;
+#endif
     np_issue(cur, 0, smem_base, dmaA, dmaW);
     bool stores_behind = false;  // the previous tile's S epilogue stores were issued after this tile's first stage
     float bz[8], bz_next[8];
@@ -625,6 +654,10 @@ __global__ __launch_bounds__(256) void gemm_nt_pair_kernel(GemmNtArgs a) {
         const bool has_next = Ln >= 0;
         Lnext = (has_next && Ln + G < total) ? Ln + G : -1;
         const bool full = (cur.m0 + NP_BM <= a.M) && (cur.n0 + NP_BN <= a.N);
+#ifdef DCV_PAIR_STAMP
+        if (tid == 0 && blockIdx.x < 1024 && n_epi < 24) np_stamps[blockIdx.x * 32 + 1 + n_epi] = __builtin_amdgcn_s_memtime();
+        ++n_epi;
+#endif
         nt_epilogue_block<EPI, 4, 4, 4, 0>(a, acc, cur.m0 + wm * 64, cur.n0 + wn * 64, r16, kg, bz, [&]() {
             if (has_next) {
                 np_tile_setup(a, Ln, tiles_n, wave, lane, nxt);
@@ -1453,8 +1486,8 @@ extern "C" int dcv_gemm_nt_resid_ln(const void* A, int lda, const void* W, int l
     if (!A || !W || !bias || !resid || !x_out || !gamma || !beta || !u_out || !mean || !rstd) return DCV_ERR_NULL;
     if (M <= 0 || K <= 0 || (K % 64) != 0 || grid_cap < 0) return DCV_ERR_SHAPE;
     if (N != N3_BN) return DCV_ERR_UNSUPPORTED;  // the tile must span whole rows
-    if ((lda % 8) || (ldw % 8) || (ldo % 4) || (ldr % 4) || (ldu % 4) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)x_out & 15) ||
-        ((uintptr_t)resid & 15) || ((uintptr_t)u_out & 7) || ((uintptr_t)bias & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15))
+    if ((lda % 8) || (ldw % 8) || (ldo % 4) || (ldr % 4) || (ldu % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)x_out & 15) ||
+        ((uintptr_t)resid & 15) || ((uintptr_t)u_out & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15))
         return DCV_ERR_ALIGN;
     if (branch_scale && (T <= 0 || (M % T) != 0)) return DCV_ERR_SHAPE;
     const int cap = grid_cap > 0 ? grid_cap : dcv_cu_count();

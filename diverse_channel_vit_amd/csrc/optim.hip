@@ -334,7 +334,7 @@ extern "C" int dcv_fill_cls(float* x, const float* cls, const float* pos0, int B
     return DCV_OK;
 }
 
-extern "C" int dcv_version(void) { return 105; }  // 1.04: round 4 (dcv_attn_bwd_fused*; round 3 removed dcv_debug_hog and gave DCV_EPI_BIAS_RESID_F32 its aux2 factor)
+extern "C" int dcv_version(void) { return 106; }  // 1.06: round 5 (dcv_attn_bwd_fused* retired to tools/probes; dcv_gemm_nt_resid_ln wants u_out 16-byte aligned, ldu % 8)
 
 extern "C" const char* dcv_error_string(int code) {
     switch (code) {

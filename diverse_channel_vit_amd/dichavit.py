@@ -365,10 +365,6 @@ class DiChaViT(nn.Module):
         self.wgrad_stream = os.environ.get("DCV_WGRAD_STREAM", "0") == "1"
         self.wgrad_private_scratch = os.environ.get("DCV_WGRAD_PRIVATE", "1") != "0"  # per-layer scratch instead of reader waits (_run_backward_body)
         self.fused_proxy_loss = os.environ.get("DCV_FUSED_PROXY_LOSS", "1") != "0"  # the channel-embedding proxy term as one kernel (dcv_proxy_loss)
-        # attention backward in one pass (dcv_attn_bwd_fused: 5 products, operands read once, dQ by an ordered, bit-reproducible hand-off).  Parity-green
-        # but measured SLOWER than the dQ + dK/dV pair at the headline shape in round 4 (1100-1500 us against 865 us per layer: the hand-off's
-        # ~5 us edge latency against a 3.6-iteration budget per edge, profiles/r04_x1_*), so it is opt-in: DCV_ATTN_BWD_FUSED=1 / model.attn_bwd_fused = True
-        self.attn_bwd_fused = os.environ.get("DCV_ATTN_BWD_FUSED", "0") == "1"
         # Pre-scaled q (round 4): the bf16 operand copy of W_q and the q part of the qkv bias are multiplied by scale * log2(e) when the copies are
         # refreshed (one rounding, as before), so the qkv GEMM delivers q' = q scale log2 e; the three attention kernels then start their score
         # accumulators at the row constants (-m, -LSE log2 e, -delta) and exp2 the accumulator directly: one vector instruction less per score in
@@ -737,7 +733,7 @@ class DiChaViT(nn.Module):
         M = B * N
         dev = x.device
         bf, f32 = torch.bfloat16, torch.float32
-        ps = bool(self.attn_prescaled) and not self.attn_bwd_fused  # pre-scaled q for this forward AND its backward (kept in the saved state)
+        ps = bool(self.attn_prescaled)  # pre-scaled q for this forward AND its backward (kept in the saved state)
         self._refresh_operand_copies(stochastic=bool(save) and self.training and self.stochastic_weight_rounding, prescale_q=ps)
         pe = fe.patch_embed
         # (channels, positions) structure of the embedding rows the tokeniser epilogue adds: (C, n) normally, (1, C*n) when the
@@ -1038,10 +1034,7 @@ class DiChaViT(nn.Module):
                     dqkv = torch.empty_like(dqkv)
                 else:
                     before_write("dqkv")
-                if self.attn_bwd_fused and not ps:
-                    hip.attn_bwd_fused(L["qkv"], L["o"], dO, L["lse"], dqkv, B, N, H, D // H, scale)
-                else:
-                    hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale, prescaled=ps)
+                hip.attn_bwd(L["qkv"], L["o"], dO, L["lse"], delta, dqkv, B, N, H, D // H, scale, prescaled=ps)
             hip.gemm_nt(dqkv, self._bf(blk.attn.qkv.weight, True), hip.EPI_PLAIN_BF16, du, **nt_kw)
             wgrad_or_collect(dqkv, L["u1"], g(blk.attn.qkv.weight), g(blk.attn.qkv.bias), "dqkv", grouped)
             if grouped:

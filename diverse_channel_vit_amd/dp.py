@@ -87,7 +87,6 @@ class DataParallel:
         self.buckets_launched = 0
         self.bytes_reduced = 0
         self._callback_queued = False
-        self._queued_in_task = -1   # autograd graph-task id of the backward pass that queued the callback
         self._poisoned = None       # set when a backward pass failed at world > 1: the ranks' collective sequences no longer match
         model._dp = self
         self._hooks = []
@@ -145,7 +144,6 @@ class DataParallel:
         if self._callback_queued:
             return
         self._callback_queued = True
-        self._queued_in_task = self._current_task()
         torch.autograd.Variable._execution_engine.queue_callback(self._engine_callback)
 
     def _engine_callback(self) -> None:
@@ -208,6 +206,22 @@ class DataParallel:
         # earlier passes left there is already the rank average, which AVG (or SUM / world) maps onto itself.
         self._reduce(q.grad)
         self.queue_finalize()
+
+    def pending_state(self) -> dict:
+        """What the reducer is waiting for, for a diagnostic line (bench.py's watchdog): the outstanding collectives with their sizes and whether
+        each has completed, the bucket being merged, the slices deferred to finalize().  Reads only; safe from another thread."""
+        works = []
+        for w, buf, _ in list(self._works):
+            done = None
+            try:
+                done = bool(w.is_completed()) if w is not None else None
+            except Exception:  # a backend without is_completed()
+                pass
+            works.append({"elements": int(buf.numel()), "dtype": str(buf.dtype).replace("torch.", ""), "completed": done})
+        pend = self._pending
+        return {"collectives_outstanding": works, "buckets_launched": self.buckets_launched,
+                "bucket_being_merged": None if pend is None else {"lo": int(pend[1]), "hi": int(pend[2])},
+                "slices_deferred": len(self._deferred), "callback_queued": bool(self._callback_queued), "poisoned": self._poisoned is not None}
 
     def _wait_all(self) -> None:
         for w, buf, dst in self._works:

@@ -54,9 +54,6 @@ _SIGS = {
     "dcv_attn_bwd_rows_ps": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_dq_rows_ps": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
     "dcv_attn_bwd_dkdv_rows_ps": ([_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp], _i),
-    "dcv_attn_bwd_fused_ws_bytes": ([_i, _i, _i], C.c_size_t),
-    "dcv_attn_bwd_fused": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp], _i),
-    "dcv_attn_bwd_fused_err_ptr": ([_vp, _i, _i, _i], _vp),
     "dcv_im2col_bf16": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
     "dcv_patch_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp], _i),
     "dcv_gather_tokens": ([_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp], _i),
@@ -391,46 +388,6 @@ def attn_bwd(qkv, o, dO, lse, delta_ws, dqkv, B, N, H, hd, scale, nq=None, presc
     with _timer(lambda: (("attn_bwd_dkdv3p_kernel" if prescaled else "attn_bwd_dkdv2_kernel<false>"), f"B{B} N{N} H{H} Nq{nq}", 3 * prod, 4 * prod, 2.0 * B * (N * 3 * D_ + nq * 1 * D_ + N * 2 * D_))):
         rc = dkdv_fn(_p(qkv), _p(dO), _p(lse), _p(delta_ws), _p(dqkv), B, N, nq, H, hd, scale, _stream())
     _check(rc, "dcv_attn_bwd_dkdv")
-
-
-_fused_ws = {}
-
-
-def attn_bwd_fused_ws(B, N, H, like: torch.Tensor) -> torch.Tensor:
-    """Scratch of the one-pass backward (statistics, hand-off flags, partial dQ tiles), one per (device, stream, shape): kernels of
-    one stream run in order and may share it.  Kept for the life of the process (a captured graph holds its address)."""
-    key = (like.device.index, torch.cuda.current_stream(like.device).cuda_stream, B, N, H)
-    ws = _fused_ws.get(key)
-    if ws is None:
-        nbytes = int(load().dcv_attn_bwd_fused_ws_bytes(B, N, H))
-        if nbytes <= 0:
-            raise ValueError("dcv_attn_bwd_fused_ws_bytes: bad shape")
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=like.device)
-        off = (-ws.data_ptr()) % 256
-        ws = ws[off:off + nbytes]
-        _fused_ws[key] = ws
-    return ws
-
-
-def attn_bwd_fused(qkv, o, dO, lse, dqkv, B, N, H, hd, scale, ws=None):
-    """dqkv from (qkv, o, dO, lse) in one pass (include/dcv.h: dcv_attn_bwd_fused); all query rows."""
-    lib = load()
-    if ws is None:
-        ws = attn_bwd_fused_ws(B, N, H, qkv)
-    prod = 2.0 * B * H * N * N * hd
-    D_ = H * hd
-    # four credited products (dP, dV, dK, dQ), five executed (S is recomputed once); bytes: qkv, o, dO read, dqkv written
-    with _timer(lambda: ("attn_bwd_fused_kernel", f"B{B} N{N} H{H}", 4 * prod, 5 * prod, 2.0 * B * N * (3 * D_ + 2 * D_ + 3 * D_))):
-        rc = lib.dcv_attn_bwd_fused(_p(qkv), _p(o), _p(dO), _p(lse), _p(ws), _p(dqkv), B, N, H, hd, scale, _stream())
-    _check(rc, "dcv_attn_bwd_fused")
-    return ws
-
-
-def attn_bwd_fused_error(ws, B, N, H) -> int:
-    """Reads the workspace's error word (synchronises): 1 = a wave gave up waiting in the last call."""
-    ptr = load().dcv_attn_bwd_fused_err_ptr(_p(ws), B, N, H)
-    off = ptr - ws.data_ptr()
-    return int(ws[off:off + 4].view(torch.int32).item())
 
 
 def im2col(x, ch_idx, out, B, Ct, C, H, W, P, scale=None, shift=None):

@@ -67,7 +67,8 @@ int dcv_gemm_tn_acc(const void* Y, int ldy, const void* X, int ldx, int M, int P
  *   x_out f32 [M,N] = resid + s (A W^T + bias)      (attn.proj / mlp.fc2 + residual, vit.py:397-398; s = branch_scale[row / T] or 1)
  *   u_out bf16 [M,N] = (x_out - mean) * rstd * gamma + beta,   mean / rstd f32 [M]   (norm2 / the next block's norm1, vit.py:397-398; eps as given)
  * = dcv_gemm_nt(DCV_EPI_BIAS_RESID_F32) + dcv_ln_fwd in one launch, without the re-read of x_out.  Statistics are centred (Chan's pairwise
- * combination), as dcv_ln_fwd's.  Returns DCV_ERR_UNSUPPORTED for N != 384. */
+ * combination), as dcv_ln_fwd's.  Returns DCV_ERR_UNSUPPORTED for N != 384.  Alignment (DCV_ERR_ALIGN otherwise): every pointer 16 bytes — u_out
+ * included: its rows leave in 16-byte stores — lda, ldw, ldu multiples of 8, ldo, ldr of 4. */
 int dcv_gemm_nt_resid_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, const float* bias, const float* resid, int ldr,
                          const float* branch_scale, int T, float* x_out, int ldo, const float* gamma, const float* beta, float eps,
                          void* u_out, int ldu, float* mean, float* rstd, int grid_cap, void* stream);
@@ -175,17 +176,6 @@ int dcv_attn_bwd_dq_rows_ps(const void* qkv, const void* o, const void* dO, cons
                             int Nq, int H, int head_dim, float scale, void* stream);
 int dcv_attn_bwd_dkdv_rows_ps(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
                               int H, int head_dim, float scale, void* stream);
-
-/* The same gradients in ONE pass (five N x N x 64 products instead of seven; Q, K, V, dO read once): one workgroup per 256 keys keeps
- * dK / dV in registers, dQ is summed across the key blocks of a (batch, head) by an ordered, bit-reproducible hand-off of f32 partial tiles
- * (no atomics) through ws.  ws: dcv_attn_bwd_fused_ws_bytes(B, N, H) bytes, 256-byte aligned, caller-owned scratch (statistics, flags and
- * partial tiles; contents are rewritten by every call).  All query rows (the Nq < N forms stay on the two-kernel path).  Returns
- * DCV_ERR_UNSUPPORTED when a chain of key blocks cannot be resident at once (N > 65 536).  dcv_attn_bwd_fused_err_ptr: device address of
- * a word the kernel sets to 1 when a wave gave up waiting for its predecessor (results then undefined; never seen on in-order dispatch). */
-size_t dcv_attn_bwd_fused_ws_bytes(int B, int N, int H);
-int dcv_attn_bwd_fused(const void* qkv, const void* o, const void* dO, const float* lse, void* ws, void* dqkv, int B, int N, int H,
-                       int head_dim, float scale, void* stream);
-const void* dcv_attn_bwd_fused_err_ptr(const void* ws, int B, int N, int H);
 
 /* x [B,Ct,H,W] f32 (x_is_u8 == 0: normalised images, the reference's batch format) or u8 (raw pixels), ch_idx int32[C]
  * (device) -> bf16 [B*C*(H/P)*(W/P), P*P] patch rows (dichavit.py:134/210,377).  scale/shift f32[C] (nullable, indexed by

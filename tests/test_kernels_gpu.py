@@ -449,84 +449,6 @@ def test_attention_fwd_bwd(hip, B, N, H):
         ref = g[:, :, i]
         tol = 3e-2 * ref.abs().max().item()
         _close(d[:, :, i], ref, 3e-2, tol, nm)
-    _fused_bwd_check(hip, qkv, o, dO, lse, g, B, N, H, scale, 3e-2)
-
-
-def _fused_bwd_check(hip, qkv, o, dO, lse, g, B, N, H, scale, tol_rel, runs=2):
-    """The one-pass backward (dcv_attn_bwd_fused) against the same fp32 gradients `g` [B, N, 3, D]; run `runs` times into NaN-filled outputs:
-    bit-identical every time (its dQ sum is an ordered hand-off, not atomics) and the error word stays 0."""
-    D = H * 64
-    outs = []
-    for _ in range(runs):
-        dq = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
-        ws = hip.attn_bwd_fused(qkv, o, dO, lse, dq, B, N, H, 64, scale)
-        assert hip.attn_bwd_fused_error(ws, B, N, H) == 0, "a wave of the fused backward gave up waiting for its predecessor"
-        outs.append(dq)
-    assert torch.isfinite(outs[0].float()).all()
-    for other in outs[1:]:
-        assert torch.equal(outs[0].view(torch.int16), other.view(torch.int16)), "fused attention backward is not bit-reproducible"
-    d = outs[0].float().reshape(B, N, 3, D)
-    for i, nm in enumerate(["dQ", "dK", "dV"]):
-        ref = g[:, :, i]
-        _close(d[:, :, i], ref, tol_rel, tol_rel * ref.abs().max().item(), nm + " (fused)")
-    return d
-
-
-@pytest.mark.parametrize("B,N,H", [(8, 1569, 6), (2, 785, 6), (3, 589, 6), (1, 256, 2), (1, 2049, 1), (5, 981, 3), (16, 289, 6)])
-def test_attention_bwd_fused_chains(hip, B, N, H):
-    """Chains of 1 .. 9 key blocks, batch x heads both a multiple of 8 (a chain per XCD) and not, more workgroups than CUs (B 8, N 1569:
-    336 workgroups — chains start apart and late members wait), a last block of one key (N = 1569, 2049, 785 = 3 x 256 + 17)."""
-    D = H * 64
-    scale = 64 ** -0.5
-    qkv = _bf(B, N, 3 * D, scale=1.3, seed=N + B)
-    dO = _bf(B, N, D, seed=11)
-    o = torch.empty(B, N, D, dtype=torch.bfloat16, device="cuda")
-    lse = torch.empty(B, H, N, device="cuda")
-    hip.attn_fwd(qkv, o, lse, B, N, H, 64, scale)
-    g = torch.empty(B, N, 3, D, device="cuda")
-    for b0 in range(0, B, 2):
-        qr = qkv[b0:b0 + 2].float().requires_grad_(True)
-        o_ref, _ = _attn_ref(qr, qr.shape[0], N, H, scale)
-        o_ref.backward(dO[b0:b0 + 2].float())
-        g[b0:b0 + 2] = qr.grad.reshape(-1, N, 3, D)
-        del qr, o_ref
-    d = _fused_bwd_check(hip, qkv, o, dO, lse, g, B, N, H, scale, 3e-2, runs=3)
-    # and against the two-kernel path: the same arithmetic except the order of the dQ sum over key blocks
-    dq2 = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device="cuda")
-    hip.attn_bwd(qkv, o, dO, lse, torch.empty(2, B, H, N, device="cuda"), dq2, B, N, H, 64, scale)
-    d2 = dq2.float().reshape(B, N, 3, D)
-    for i, nm in enumerate(["dQ", "dK", "dV"]):
-        rel = ((d[:, :, i] - d2[:, :, i]).norm() / d2[:, :, i].norm()).item()
-        assert rel <= 6e-3, (nm, rel)
-
-
-def test_attention_bwd_fused_under_uneven_load(hip):
-    """The hand-off under load that is NOT uniform (cdna guide, Guideline 16 pitfall 3): a second stream keeps part of the chip busy with
-    GEMMs while the fused backward runs, the consumer's lines are warm from a previous call, results must stay bit-identical to the quiet run."""
-    B, N, H = 16, 1569, 6
-    D = H * 64
-    scale = 64 ** -0.5
-    qkv = _bf(B, N, 3 * D, scale=1.2, seed=5)
-    dO = _bf(B, N, D, seed=6)
-    o = torch.empty(B, N, D, dtype=torch.bfloat16, device="cuda")
-    lse = torch.empty(B, H, N, device="cuda")
-    hip.attn_fwd(qkv, o, lse, B, N, H, 64, scale)
-    quiet = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device="cuda")
-    ws = hip.attn_bwd_fused(qkv, o, dO, lse, quiet, B, N, H, 64, scale)
-    torch.cuda.synchronize()
-    assert hip.attn_bwd_fused_error(ws, B, N, H) == 0
-    side = torch.cuda.Stream()
-    A = _bf(8192, 1024, seed=1)
-    Wt = _bf(1024, 1024, seed=2)
-    for rep in range(6):
-        busy = torch.empty(B, N, 3 * D, dtype=torch.bfloat16, device="cuda")
-        with torch.cuda.stream(side):
-            for _ in range(2 + 3 * (rep % 3)):
-                A @ Wt
-        hip.attn_bwd_fused(qkv, o, dO, lse, busy, B, N, H, 64, scale, ws=ws)
-        torch.cuda.synchronize()
-        assert hip.attn_bwd_fused_error(ws, B, N, H) == 0
-        assert torch.equal(busy.view(torch.int16), quiet.view(torch.int16)), f"rep {rep}: differs from the quiet run"
 
 
 def test_attention_at_the_bench_grid(hip):
@@ -567,17 +489,25 @@ def test_attention_at_the_bench_grid(hip):
         del qr, o_ref, lse_ref, g
     print("attention at B64 H6 N1569: worst relative L2 error per 4-image chunk", {k: f"{v:.2e}" for k, v in worst.items()})
     assert all(v <= 1e-2 for v in worst.values())
-    # the one-pass backward at the same grid (2 688 workgroups in chains of 7): against the pair's result, which was just checked
-    dqf = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
-    ws = hip.attn_bwd_fused(qkv, o, dO, lse, dqf, B, N, H, 64, scale)
-    assert hip.attn_bwd_fused_error(ws, B, N, H) == 0
-    dqf2 = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
-    hip.attn_bwd_fused(qkv, o, dO, lse, dqf2, B, N, H, 64, scale)
-    assert torch.equal(dqf.view(torch.int16), dqf2.view(torch.int16)), "fused attention backward is not bit-reproducible at the bench grid"
-    a3, b3 = dqf.float().reshape(B, N, 3, D), dqkv.float().reshape(B, N, 3, D)
+    # the pre-scaled-q entries at the same grid — the backward's dK / dV there is the persistent third form (csrc/attn_bwd3.hip: 2 304 items of 256 keys on
+    # 256 workgroups, nine each, the 33-key remainder through the second form): against the plain pair's result, which was just checked
+    c = scale * math.log2(math.e)
+    qs = qkv.clone()
+    qs[:, :, :D] = (qkv[:, :, :D].float() * c).to(torch.bfloat16)
+    o_ps = torch.empty_like(o)
+    lse_ps = torch.empty_like(lse)
+    hip.attn_fwd(qs, o_ps, lse_ps, B, N, H, 64, scale, prescaled=True)
+    outs = []
+    for _ in range(2):
+        dps = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+        hip.attn_bwd(qs, o_ps, dO, lse_ps, torch.empty(2, B, H, N, device="cuda"), dps, B, N, H, 64, scale, prescaled=True)
+        outs.append(dps)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), "pre-scaled attention backward is not bit-reproducible at the bench grid"
+    a3, b3 = outs[0].float().reshape(B, N, 3, D), dqkv.float().reshape(B, N, 3, D)
     relf = {nm: ((a3[:, :, i] - b3[:, :, i]).norm() / b3[:, :, i].norm()).item() for i, nm in enumerate(["dQ", "dK", "dV"])}
-    print("fused vs pair at the bench grid, relative L2:", {k: f"{v:.2e}" for k, v in relf.items()})
-    assert all(v <= 6e-3 for v in relf.values())
+    print("pre-scaled q vs plain at the bench grid, relative L2:", {k: f"{v:.2e}" for k, v in relf.items()})
+    assert all(v <= 1.2e-2 for v in relf.values())  # the two q operands differ by one bf16 rounding of q * scale * log2(e)
 
 
 def test_im2col(hip):
@@ -742,14 +672,18 @@ def test_attention_long_sequence_base_heads(hip):
         ref = g[:, :, i]
         rel = (d[:, :, i] - ref).norm().item() / ref.norm().item()
         assert rel <= 2e-2, (nm, rel)
-    dqf = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
-    ws = hip.attn_bwd_fused(qkv, o, dO, lse, dqf, B, N, H, 64, scale)  # chains of 50 key blocks (not XCD-local: J > 32)
-    assert hip.attn_bwd_fused_error(ws, B, N, H) == 0
-    df = dqf.float().reshape(B, N, 3, D)
+    # the pre-scaled-q pair at this length (dK / dV: the persistent form, 2 x 50 items of 256 keys on 100 workgroups; 197 query tiles per item)
+    c = scale * math.log2(math.e)
+    qs = qkv.clone()
+    qs[:, :, :D] = (qkv[:, :, :D].float() * c).to(torch.bfloat16)
+    hip.attn_fwd(qs, o, lse, B, N, H, 64, scale, prescaled=True)
+    dps = torch.full((B, N, 3 * D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hip.attn_bwd(qs, o, dO, lse, delta, dps, B, N, H, 64, scale, prescaled=True)
+    df = dps.float().reshape(B, N, 3, D)
     for i, nm in enumerate(["dQ", "dK", "dV"]):
         ref = g[:, :, i]
         rel = (df[:, :, i] - ref).norm().item() / ref.norm().item()
-        assert rel <= 2e-2, (nm + " fused", rel)
+        assert rel <= 2e-2, (nm + " pre-scaled q", rel)
 
 
 def _lowbias32(h):
@@ -836,6 +770,36 @@ def test_attention_prescaled_q(hip, B, N, H, Nq, shift):
     for i, nm in enumerate(["dQ", "dK", "dV"]):
         ref = g[:, :, i]
         _close(d[:, :, i], ref, 3e-2, 3e-2 * ref.abs().max().item(), "ps " + nm)
+
+
+def test_attention_prescaled_q_first_tile_far_below_the_maximum(hip):
+    """in the pre-scaled-q forward the reference maximum of tile 0 is the tile's own maximum whatever its sign; when EVERY score of the first
+    64 keys lies below -127 in log2 units (natural logit < -88) the rescale factor exp2(-d) of that tile is +inf while l and O are still 0, and
+    0 * inf = NaN reached l, O and LSE.  Here the first 64 keys score -128 (natural) against every query of head 0 and later tiles hold the maximum:
+    the pre-scaled entry must equal the plain one and the fp32 definition (and stay finite)."""
+    B, N, H = 2, 200, 2
+    D = H * 64
+    scale = 64 ** -0.5
+    c = scale * math.log2(math.e)
+    qkv = _bf(B, N, 3 * D, scale=0.5, seed=91)
+    qkv[:, :, :64] = 1.0          # head 0: q = 1 in every component ...
+    qkv[:, :64, D:D + 64] = -16.0  # ... keys 0..63: score 64 * -16 / 8 = -128
+    qs = qkv.clone()
+    qs[:, :, :D] = (qkv[:, :, :D].float() * c).to(torch.bfloat16)
+    qref = qs.float()
+    qref[:, :, :D] /= c
+    o_ref, lse_ref = _attn_ref(qref, B, N, H, scale)
+    o = torch.full((B, N, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lse = torch.full((B, H, N), float("nan"), device="cuda")
+    hip.attn_fwd(qs, o, lse, B, N, H, 64, scale, prescaled=True)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    _close(o, o_ref, 2e-2, 2e-2, "ps attn O, deep first tile")
+    _close(lse, lse_ref, 1e-4, 3e-3, "ps attn LSE, deep first tile")
+    o2 = torch.empty_like(o)
+    lse2 = torch.empty_like(lse)
+    hip.attn_fwd(qkv, o2, lse2, B, N, H, 64, scale)  # the plain entry on the unscaled operand
+    _close(o, o2, 2e-2, 2e-2, "ps vs plain O")
+    _close(lse, lse2, 1e-4, 5e-2, "ps vs plain LSE")  # the two operands differ by the bf16 rounding of q * c
 
 
 def test_cast_scaled_ranges(hip):

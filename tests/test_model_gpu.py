@@ -8,6 +8,7 @@ Stated tolerance (north_star: "within a stated bf16/fp32 tolerance"): activation
   per-parameter gradient: relative L2 error <= 5e-2 and cosine >= 0.998 (tensors with norm above a floor).
 Needs an MI355X (-m gpu)."""
 import math
+import os
 import random
 
 import numpy as np
@@ -447,11 +448,13 @@ def test_plugin_contract(gpu_device):
         model(x.cpu(), "train", None)
 
 
-def _run_curve(gpu_device, name, stochastic):
+def _run_curve(gpu_device, name, stochastic, seed=None):
     import diverse_channel_vit_amd as dcv
     meta, a = load_golden(name)
     model, _ = build(meta, gpu_device)
     model.stochastic_weight_rounding = stochastic
+    if seed is not None:  # the draw of the stochastic weight rounding (cfg.weight_rounding_seed; 1 by default)
+        model._sr_seed = torch.full((1,), int(seed), dtype=torch.int32, device=gpu_device)
     opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=meta["lr"], weight_decay=meta["wd"],
                        betas=tuple(meta["betas"]), eps=meta["eps"], model=model)
     batches = [orc.make_batch(meta["seed"] + 100 + i, meta["B"], meta["n_channels"], meta["img"], meta["num_classes"]) for i in range(meta["n_batches"])]
@@ -534,28 +537,78 @@ def test_loss_curve_headline_architecture(gpu_device):
 
 
 def test_loss_curve_distinct_batches_headline_architecture(gpu_device):
-    """north_star's criterion — the 100-step loss curve within 1e-3 of the reference — on a curve that can carry it:
-    the headline architecture (DiChaViT-S, 8 ch, 224^2, 161 classes) at batch 8 over 100 DISTINCT batches (tests/golden/
-    curve100_jumpcp_s_b8.npz, generated by the real reference: trainer.py:963-1028's step, lr 4.9e-5, wd 0.04).  No batch is seen twice, so
-    nothing is memorised: the loss stays near ln 161 (5.02 .. 5.5), single steps do not amplify rounding differences, and the comparison
-    measures the arithmetic of the path rather than the conditioning of a trajectory (the batch-2 curve above keeps a smoke bound only).
-    Asserted: mean |err| <= 1e-3 and every one of the last 20 steps <= 1e-3; the largest single-step error is printed and bounded at
-    the value stated below.  Bounds are FROZEN at round 4's values: a later build that exceeds them is a finding to explain, not a number to re-fit."""
+    """The headline architecture (DiChaViT-S, 8 ch, 224^2, 161 classes) at batch 8 over 100 DISTINCT batches (tests/golden/curve100_jumpcp_s_b8.npz,
+    generated by the real reference: trainer.py:963-1028's step, lr 4.9e-5, wd 0.04).  No batch is seen twice: the loss stays near ln 161 and
+    the comparison measures the arithmetic of the path rather than the conditioning of a memorising trajectory.
+
+    What is asserted HERE is weaker than north_star's criterion, and says so: at batch 8 the per-step error moves with the DRAW of the
+    stochastic weight rounding as much as with the build — five rounding seeds x {plain, pre-scaled q} (profiles/r04_x6_*): mean 3.4e-4 .. 4.5e-4,
+    maximum of the last 20 steps 5.8e-4 .. 1.06e-3 (three of ten draws above 1e-3), worst step 1.44e-3 .. 1.92e-3, 3 .. 11 steps above 1e-3.  So:
+    the MEAN meets 1e-3 with a factor two to spare on every draw; "every one of the last 20 steps within 1e-3" does NOT hold on every draw at
+    this batch size and is bounded at 1.3e-3.  north_star states the criterion at bs 64; the per-step error is a batch mean and the draw-to-draw
+    spread falls with the batch size (profiles/r05_x1_*): test_loss_curve_north_star_criterion asserts the criterion itself, unweakened, at bs 16
+    and bs 32 on three rounding seeds each.  These bs-8 bounds were set from the ten-draw spread in round 4 and may only be tightened."""
     e_sr, ref = _run_curve(gpu_device, "curve100_jumpcp_s_b8", True)
     _curve_report("loss-curve headline bs8 distinct, stochastic", e_sr, ref)
-    # History of the bounds.  Frozen first at one draw per build (deterministic mode, bit-reproducible on a build): 4.52e-4 / max 1.519e-3 / mean
-    # 3.927e-4 / last 20 <= 7.477e-4 / 3 steps above 1e-3, and with the LayerNorm as a separate launch 2.90e-4 / 2.304e-3 / 3.927e-4 / 7.453e-4 / 6;
-    # bounds "last 20 <= 1e-3" and "<= 8 steps above 1e-3".  The pre-scaled-q build then gave 11 steps above 1e-3 — the finding: the statistics
-    # of this curve move with the DRAW of the stochastic weight rounding as much as with the build.  Five rounding seeds x {plain, pre-scaled q}
-    # (tools/curve_seeds.py, profiles/r04_x6_loss_curve_seed_spread.txt): mean 3.4e-4 .. 4.5e-4 (both builds), last-20 maximum 5.8e-4 .. 1.06e-3
-    # (three of ten runs above 1e-3, by at most 6 %), worst step 1.44e-3 .. 1.92e-3, steps above 1e-3: 3 .. 11.  So: the mean meets north_star's
-    # 1e-3 with a factor 2 to spare on every draw; "every one of the last 20 steps" holds for 7 draws of 10 and is bounded at 1.3e-3; the
-    # single-step bounds are set from the ten-run spread, not from one draw.
-    assert e_sr.mean() <= 6e-4, e_sr.mean()             # north_star's 1e-3 on the mean, frozen at 1.3 x the worst of ten draws (4.5e-4)
-    assert e_sr[-20:].max() <= 1.3e-3, e_sr[-20:].max()   # 1.2 x the worst of ten draws
+    assert e_sr.mean() <= 6e-4, e_sr.mean()               # north_star's 1e-3 on the mean (worst of ten draws 4.5e-4)
+    assert e_sr[-20:].max() <= 1.3e-3, e_sr[-20:].max()   # NOT north_star's 1e-3: 1.2 x the worst of ten draws
     assert e_sr[-20:].mean() <= 6e-4, e_sr[-20:].mean()
-    assert e_sr.max() <= 2.8e-3, e_sr.max()             # unchanged (worst of ten draws 1.92e-3)
-    assert int((e_sr > 1e-3).sum()) <= 14               # 3 .. 11 over ten draws
+    assert e_sr.max() <= 2.8e-3, e_sr.max()               # worst of ten draws 1.92e-3
+    assert int((e_sr > 1e-3).sum()) <= 14                 # 3 .. 11 over ten draws
+
+
+@pytest.mark.parametrize("name", ["curve100_jumpcp_s_b16", "curve100_jumpcp_s_b32"])
+def test_loss_curve_north_star_criterion(gpu_device, name):
+    """north_star: "100-step loss curve within 1e-3 of reference" (quoted at bs 64 per GPU).  VERDICT r4 item 5: test the criterion where it is
+    stated instead of re-fitting bounds at bs 8.  Headline architecture, 100 DISTINCT batches from the real reference (trainer.py:963-1028's step,
+    train_scripts.sh:5's first-epoch lr) at bs 16 and bs 32 — the largest the reference's CPU path produces here in bounded time (50 min / 2.4 h of
+    reference CPU time, 24 / 45 GB of host memory; bs 64 would need > 64 GB).  Three draws of the stochastic weight rounding each; on EVERY draw:
+    mean |err| <= 1e-3 and every one of the last 20 steps <= 1e-3.  These two bounds are the criterion, not fitted numbers; the maximum over all
+    100 steps is printed and bounded only loosely (early steps carry the un-averaged first-forward difference).  An exceedance is a finding for
+    DESIGN section 4, not a new constant."""
+    if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz")):
+        pytest.skip(name + ".npz not generated (tests/golden/make_golden.py " + name.replace("curve100_jumpcp_s", "curve_jumpcp") + ")")
+    worst = 0.0
+    for seed in (1, 2, 3):
+        e, ref = _run_curve(gpu_device, name, True, seed=seed)
+        _curve_report(f"loss-curve {name} rounding seed {seed}", e, ref)
+        assert e.mean() <= 1e-3, (seed, e.mean())
+        assert e[-20:].max() <= 1e-3, (seed, e[-20:].max())
+        worst = max(worst, e.max())
+    print(f"{name}: largest single-step |err| over three draws {worst:.3e}")
+    assert worst <= 3e-3, worst
+
+
+def test_loss_curve_prescaled_q_gap(gpu_device):
+    """the round that moved the attention arithmetic (pre-scaled q, round 4) also widened curve bounds; this pins what that path may
+    cost, at a FIXED rounding seed: the bs-16 headline curve with the pre-scaled-q attention (default) and with the plain entries
+    (model.attn_prescaled = False) both meet the criterion, and their mean errors differ by less than the draw-to-draw spread (3e-4)."""
+    import diverse_channel_vit_amd as dcv
+    name = "curve100_jumpcp_s_b16"
+    stats = {}
+    for ps in (True, False):
+        meta, a = load_golden(name)
+        model, _ = build(meta, gpu_device)
+        model.attn_prescaled = ps
+        model._sr_seed = torch.full((1,), 1, dtype=torch.int32, device=gpu_device)
+        opt = dcv.HipAdamW([p for p in model.parameters() if p.requires_grad], lr=meta["lr"], weight_decay=meta["wd"], betas=tuple(meta["betas"]),
+                           eps=meta["eps"], model=model)
+        ref = a["losses"][:, 0]
+        e = []
+        for s_ in range(meta["steps"]):
+            x, y = orc.make_batch(meta["seed"] + 100 + s_, meta["B"], meta["n_channels"], meta["img"], meta["num_classes"])
+            x, y = x.to(gpu_device), y.to(gpu_device)
+            opt.zero_grad()
+            out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+            loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+            loss.backward()
+            opt.step()
+            e.append(abs(loss.item() - ref[s_]))
+        e = np.array(e)
+        _curve_report(f"loss-curve bs16 pre-scaled q = {ps}", e, ref)
+        assert e.mean() <= 1e-3 and e[-20:].max() <= 1e-3, (ps, e.mean(), e[-20:].max())
+        stats[ps] = e.mean()
+    assert abs(stats[True] - stats[False]) <= 3e-4, stats
 
 
 @pytest.mark.parametrize("rounding", ["nearest", "stochastic"])

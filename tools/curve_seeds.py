@@ -34,6 +34,21 @@ def run(name, ps, seed, stochastic=True):
     return np.array(errs)
 
 
+if os.environ.get("CS_BATCH_SCALING"):  # round 5: the headline distinct-batch curves at bs 8 / 16 / 32 (default build), spread over rounding seeds
+    rows = []
+    for name in ("curve100_jumpcp_s_b8", "curve100_jumpcp_s_b16", "curve100_jumpcp_s_b32"):
+        if not os.path.exists(os.path.join(ROOT, "tests", "golden", name + ".npz")):
+            continue
+        es = []
+        for seed in seeds:
+            e = run(name, True, seed)
+            es.append(e)
+            print(f"{name:24s} seed={seed}: step0 {e[0]:.2e} max {e.max():.3e} mean {e.mean():.3e} tail20 max {e[-20:].max():.3e} tail20 mean {e[-20:].mean():.3e} above1e-3 {int((e > 1e-3).sum())}", flush=True)
+        es = np.array(es)
+        rows.append((name, es))
+        print(f"  -> over {len(seeds)} draws: mean {es.mean(1).min():.2e} .. {es.mean(1).max():.2e}; last-20 max {es[:, -20:].max(1).min():.2e} .. {es[:, -20:].max(1).max():.2e};"
+              f" worst step {es.max(1).min():.2e} .. {es.max(1).max():.2e}; rms over steps 20..99 and draws {np.sqrt((es[:, 20:] ** 2).mean()):.3e}", flush=True)
+    sys.exit(0)
 for name in ("curve100_jumpcp_s_b8", "curve100_so2sat_s_distinct"):
     for ps in (False, True):
         for seed in seeds:

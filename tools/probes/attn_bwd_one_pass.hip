@@ -1,3 +1,6 @@
+// RETIRED from the product library in round 5: the one-pass attention backward (dQ by an ordered hand-off between key-block workgroups).
+// Parity-green but 28-70 % slower than the dQ + dK/dV pair wherever measured (profiles/r04_x1_*); kept here as the record of that experiment.  It built as
+// csrc/attn_bwd_fused.hip against include/dcv.h of round 4 (three entries: dcv_attn_bwd_fused, _ws_bytes, _err_ptr), which no longer declares them.
 // Attention backward in ONE pass for head_dim 64 on gfx950: five N x N x 64 products per (batch, head) instead of the seven of the
 // dQ + dK/dV pair in attn_bwd.hip, and Q / K / V / dO are read once.  Reference semantics: models/vit.py:121-144 (the backward of
 // softmax(q k^T * hd^-0.5) v as autograd computes it).
