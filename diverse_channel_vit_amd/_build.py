@@ -17,7 +17,8 @@ EXTRA = {"attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
          # (dK/dV kernel 4 % slower); the forward keeps it (its packed forms are written out and measured 2 % faster)
          "attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
          # third dK/dV form: its MFMAs are inline asm with explicit register classes; the flag keeps hipcc's own choices out of the accumulator file
-         "attn_bwd3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
+         "attn_bwd3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
+         "attn_bwd3q.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"]}
 
 
 def sources():

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     __shared__ __attribute__((aligned(16))) char sKV[DQ_STAGES * KV_STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, r32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nqt = (a.N + 127) / 128;  // all query tiles: those beyond Nq only clear their dQ rows (dqkv is fully defined)
+    const int nqt = (a.N - a.key_lo + 127) / 128;  // query tiles launched: rows [key_lo, N); those beyond Nq only clear their dQ rows (dqkv is fully defined)
     const int BH = a.B * a.H;
     int bh, qt;
     if ((BH & 7) == 0) {
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
         bh = blockIdx.x / nqt;
         qt = blockIdx.x % nqt;
     }
+    qt += a.key_lo / 128;
     const int b = bh / a.H, hh = bh % a.H;
     const int D = a.H * 64;
     const size_t rs = (size_t)3 * D;
@@ -443,6 +444,9 @@ static int dq_launch(const void* qkv, const void* o, const void* dO, const float
     if (!dqkv) return DCV_ERR_NULL;
     if (Nq < 1 || Nq > N) return DCV_ERR_SHAPE;
     AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
+#if DCV_DQ_FORM == 3
+    if (ps && Nq == N) return dcv_dq3_launch(qkv, o, dO, lse, ws, dqkv, B, N, H, scale, (hipStream_t)stream);  // attn_bwd3q.hip (round 5); same sums, same order
+#endif
     const dim3 grid(B * H * ((N + 127) / 128));
     if (ps) hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(attn_bwd_dq2_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
@@ -465,6 +469,18 @@ static int dkdv_launch(const void* qkv, const void* dO, const float* lse, const 
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }
+
+#if DCV_DQ_FORM == 3
+__attribute__((visibility("hidden"))) int dcv_dq2_range(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int H, float scale,
+                                                        int row_lo, hipStream_t stream) {
+    AttnArgs a{(const bf16_t*)qkv, (bf16_t*)o, (const bf16_t*)dO, (float*)lse, ws, (bf16_t*)dqkv, B, N, H, scale, N};
+    a.key_lo = row_lo;  // for the dQ kernel the range is one of query rows
+    hipLaunchKernelGGL(attn_bwd_dq2_kernel<true>, dim3(B * H * ((N - row_lo + 127) / 128)), dim3(256), 0, stream, a);
+    DCV_LAUNCH_CHECK();
+    return DCV_OK;
+}
+
+#endif
 
 __attribute__((visibility("hidden"))) int dcv_dkdv2_range(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq, int H, float scale, int key_lo,
                     hipStream_t stream) {

@@ -25,7 +25,7 @@
 // region R (tiles nt-12 .. nt-5) and become register fragments at the seam; dK / dV leave the accumulators at the seam into the same region (bf16,
 // row = key) and go to HBM as whole 128-byte rows, two store instructions per tile over the next item's first eight tiles.  (All 256 workgroups
 // run in lockstep: with the loads and stores AT the seam every CU hit HBM at once while no CU computed — 68 of 418 us, timing-only ablation.)
-#include "attn_common.hpp"
+#include "attn3_common.hpp"
 
 namespace {
 
@@ -40,7 +40,6 @@ constexpr int P3_R_BYTES = 16384;  // per-wave region R: next item's K tile | V 
 __device__ unsigned long long k3_stamps[1024 * 8];
 #define K3_NOW() __builtin_amdgcn_s_memtime()
 #endif
-#define P3_FENCE() __builtin_amdgcn_sched_barrier(0)
 // even step, gap g: which of the 16 row / statistics reads (load_rows index: 0-3 stl, 4-7 std_, 8-11 rq, 12-15 rdo) and which of the 8 transposed
 // reads go out.  A register is reloaded only after the MFMA that last read it: stl / std_ (C operands of MFMA 0 / 1) from gap 2, rq[ks] after
 // MFMA 2 ks, rdo[ks] after MFMA 2 ks + 1.
@@ -48,23 +47,6 @@ constexpr int P3_ROWS_AT[16][2] = {{-1, -1}, {-1, -1}, {0, 1}, {2, 3}, {4, 5}, {
                                    {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}};
 constexpr int P3_TR0_AT[16][2] = {{0, -1}, {1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1}, {-1, -1},
                                   {2, -1}, {3, -1}, {4, -1}, {5, -1}, {6, 7}};
-#define P3_PIN(x) asm volatile("" : "+v"(x))
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {  // one v_cvt_pk_bf16_f32
-    bf16x2_t v;
-    v[0] = (bf16_t)lo;
-    v[1] = (bf16_t)hi;
-    return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ void mfma_vv(f32x16& d, const bf16x8& a, const bf16x8& b) {  // d += a b   (d in arch VGPRs, b = K / V fragment in AGPRs)
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
-}
-__device__ __forceinline__ void mfma_vc(f32x16& d, const bf16x8& a, const bf16x8& b, const f32x16& c) {  // d = a b + c
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "a"(b), "v"(c));
-}
-__device__ __forceinline__ void mfma_aa(f32x16& d, const bf16x8& a, const bf16x8& b) {  // d += a b   (d in AGPRs)
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
-}
 struct K3Item {  // wave-uniform description of one (batch-head, key block); pointers are rebuilt from it where needed (SGPR budget)
     int b, hh, key0;  // key0: first key of this WAVE
     bool valid;

@@ -134,6 +134,14 @@ __attribute__((visibility("hidden"))) int dcv_dkdv2_range(const void* qkv, const
 // attn_bwd3.hip: the third dK / dV form (pre-scaled q): persistent, one wave per SIMD; all keys (the remainder of < 129 keys through dcv_dkdv2_range)
 __attribute__((visibility("hidden"))) int dcv_dkdv3_launch(const void* qkv, const void* dO, const float* lse, const float* ws, void* dqkv, int B, int N, int Nq,
                                                            int H, float scale, hipStream_t stream);
+// the dQ counterparts (attn_bwd.hip for query rows [row_lo, N), row_lo a multiple of 128; attn_bwd3q.hip for all rows, Nq == N)
+__attribute__((visibility("hidden"))) int dcv_dq2_range(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int H, float scale,
+                                                        int row_lo, hipStream_t stream);
+__attribute__((visibility("hidden"))) int dcv_dq3_launch(const void* qkv, const void* o, const void* dO, const float* lse, float* ws, void* dqkv, int B, int N, int H,
+                                                         float scale, hipStream_t stream);
+#ifndef DCV_DQ_FORM
+#define DCV_DQ_FORM 2  // 3 (variant builds only): the one-wave-per-SIMD dQ kernel of attn_bwd3q.hip — bit-identical, measured 1-11 % SLOWER (profiles/r05_x4_*)
+#endif
 #ifndef DCV_DKDV_FORM
 #define DCV_DKDV_FORM 3  // 2: dcv_attn_bwd_dkdv_rows_ps keeps the second form (A/B builds)
 #endif

@@ -33,6 +33,17 @@ def prep(h, d, nq):
     dq = torch.zeros_like(d["qkv"])
     rc = h.dcv_attn_bwd_dq_rows_ps(p(d["qkv"]), p(d["o"]), p(d["dO"]), p(d["lse"]), p(d["ws"]), p(dq), d["B"], d["N"], nq, d["H"], 64, C.c_float(0.125), st)
     assert rc == 0, rc
+    torch.cuda.synchronize()
+    return dq, d["ws"].clone()
+
+
+def run_dq(h, d, nq):
+    dq = torch.full_like(d["qkv"], float("nan"))
+    ws = torch.full_like(d["ws"], float("nan"))
+    rc = h.dcv_attn_bwd_dq_rows_ps(p(d["qkv"]), p(d["o"]), p(d["dO"]), p(d["lse"]), p(ws), p(dq), d["B"], d["N"], nq, d["H"], 64, C.c_float(0.125), st)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return dq, ws
 
 
 def run(h, name, d, nq):
@@ -48,7 +59,16 @@ href = C.CDLL(os.path.join(ROOT, "diverse_channel_vit_amd", "libdcv_hip_dkdv2.so
 ok = True
 for (B, N, H, nq) in [(1, 64, 1, 64), (2, 256, 2, 256), (1, 77, 3, 77), (2, 320, 6, 320), (3, 1569, 6, 1569), (2, 1569, 6, 1), (2, 600, 6, 33), (1, 4100, 2, 4100)]:
     d = make(B, N, H, seed=N)
-    prep(h0, d, nq)
+    dq_ref, ws_ref = prep(href, d, nq)
+    for h, l in zip(hs, libs):  # dQ (query rows < nq; the rest zero) and the workspace rows, third form against second
+        dq_new, ws_new = run_dq(h, d, nq)
+        D_ = 64 * H
+        a, b_ = dq_ref[:, :, :D_].float(), dq_new[:, :, :D_].float()
+        bad = int((torch.isnan(b_) | (a != b_)).sum())
+        wa, wb = ws_ref[:, :, :, :nq], ws_new[:, :, :, :nq]
+        wbad = int((torch.isnan(wb) | (wa != wb)).sum())
+        print(f"B{B} N{N} H{H} Nq{nq} {os.path.basename(l)}: dQ mismatching {bad} of {a.numel()}  max|diff| {float((a - b_).abs().nan_to_num(1e30).max()):.3g}   workspace mismatching {wbad} of {wa.numel()}", flush=True)
+        ok &= bad == 0 and wbad == 0
     ref = run(href, "dcv_attn_bwd_dkdv_rows_ps", d, nq)
     for h, l in zip(hs, libs):
         new = run(h, "dcv_attn_bwd_dkdv_rows_ps", d, nq)
@@ -64,16 +84,20 @@ if os.environ.get("A3_TIME", "1") != "0":
     for zero in (False, True):
         for N in (1536, 1569):
             d = make(64, N, 6, zero=zero)
-            prep(h0, d, N)
+            prep(href, d, N)
             out = torch.empty_like(d["qkv"])
             names = [(href, "dcv_attn_bwd_dkdv_rows_ps", "dkdv2")] + [(h, "dcv_attn_bwd_dkdv_rows_ps", "dkdv3:" + os.path.basename(l)) for h, l in zip(hs, libs)]
+            names += [(href, "DQ", "dq2")] + [(h, "DQ", "dq3:" + os.path.basename(l)) for h, l in zip(hs, libs)]
             res = {n[2]: [] for n in names}
             for rnd in range(14):
                 for h, fn, tag in names:
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
                     for _ in range(3):
-                        getattr(h, fn)(p(d["qkv"]), p(d["dO"]), p(d["lse"]), p(d["ws"]), p(out), 64, N, N, 6, 64, C.c_float(0.125), st)
+                        if fn == "DQ":
+                            h.dcv_attn_bwd_dq_rows_ps(p(d["qkv"]), p(d["o"]), p(d["dO"]), p(d["lse"]), p(d["ws"]), p(out), 64, N, N, 6, 64, C.c_float(0.125), st)
+                        else:
+                            getattr(h, fn)(p(d["qkv"]), p(d["dO"]), p(d["lse"]), p(d["ws"]), p(out), 64, N, N, 6, 64, C.c_float(0.125), st)
                     e.record()
                     torch.cuda.synchronize()
                     if rnd >= 2:
