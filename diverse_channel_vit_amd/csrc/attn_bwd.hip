@@ -243,7 +243,11 @@ constexpr int DKV_STAGES = 4, DKV_STAGE_BYTES = 16384 + 1024;  // Q tile | dO ti
 constexpr int DKV_DMA_PER_WAVE = 5;
 // PS: q pre-scaled (see above); the workspace rows hold -LSE * log2(e) and are read straight into the score accumulator; dK leaves with 1 / log2(e)
 // (dK = scale dS^T Q = dS^T Q' / log2 e).
-template <bool PS>
+// TAIL2 (round 5): the launch for a key remainder of at most 64 keys per (batch, head) behind the third form (dcv_dkdv2_range).  There only two of
+// the four waves had keys and every workgroup swept all query tiles alone on its CU: 52 us for 2 % of the keys.  With TAIL2 wave w takes key block
+// w & 1 and the 32-query block w >> 1 of every tile — half the sweep per wave — and waves 2, 3 hand their partial dK / dV to waves 0, 1 through LDS at
+// the end (one fixed order: deterministic; not the sequential order of the plain mode).
+template <bool PS, bool TAIL2 = false>
 #if DCV_WPE_DKDV
 DCV_WAVES_PER_SIMD(DCV_WPE_DKDV)
 #endif
@@ -303,9 +307,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         glds4s(st, s0, stat_dst + slot * DKV_STAGE_BYTES);
     };
 
-    const int key = kt * 128 + wave * 32 + r32;  // this lane's key
+    const int kblk = TAIL2 ? (wave & 1) : wave;     // this wave's 32-key block inside the workgroup's key tile
+    const int key = kt * 128 + kblk * 32 + r32;    // this lane's key
     const int kc = min(key, a.N - 1);
-    const bool active = kt * 128 + wave * 32 < a.N;  // a wave without a single valid key only keeps the ring going
+    const bool active = kt * 128 + kblk * 32 < a.N;  // a wave without a single valid key only keeps the ring going
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -344,6 +349,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         const int sto = so + 16384 + 16 * h;  // this lane-half's 4 consecutive query rows inside an 8-row group
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            if (TAIL2 && qb != (wave >> 1)) continue;  // wave-uniform: the other query block is the partner wave's
             f32x16 s, dp;
             f32x4 l4[4];
             if constexpr (!PS) zero_acc(s);
@@ -400,6 +406,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv2_kernel(AttnArgs a) {
         if (nfull < nt) tile(Yes{}, No{}, nfull, nfull & 3);
     }
 
+    if constexpr (TAIL2) {  // waves 2, 3 -> LDS -> waves 0, 1 (the ring is idle: every wave is past its last tile)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(sQO) + (wave & 1) * 64 * 64;  // [register][lane], 16 KB per key block
+        if (wave >= 2) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    red[(dt * 16 + r) * 64 + lane] = dk[dt][r];
+                    red[(32 + dt * 16 + r) * 64 + lane] = dv[dt][r];
+                }
+        }
+        __syncthreads();
+        if (wave >= 2) return;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dk[dt][r] += red[(dt * 16 + r) * 64 + lane];
+                dv[dt][r] += red[(32 + dt * 16 + r) * 64 + lane];
+            }
+    }
     if (key < a.N) {
         bf16_t* dkp = a.dqkv + ((size_t)b * a.N + key) * rs + D + hh * 64;
         bf16_t* dvp = dkp + D;
@@ -486,7 +514,8 @@ __attribute__((visibility("hidden"))) int dcv_dkdv2_range(const void* qkv, const
                     hipStream_t stream) {
     AttnArgs a{(const bf16_t*)qkv, nullptr, (const bf16_t*)dO, (float*)lse, (float*)ws, (bf16_t*)dqkv, B, N, H, scale, Nq};
     a.key_lo = key_lo;
-    hipLaunchKernelGGL(attn_bwd_dkdv2_kernel<true>, dim3(B * H * ((N - key_lo + 127) / 128)), dim3(256), 0, stream, a);
+    if (N - key_lo <= 64) hipLaunchKernelGGL((attn_bwd_dkdv2_kernel<true, true>), dim3(B * H), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(attn_bwd_dkdv2_kernel<true>, dim3(B * H * ((N - key_lo + 127) / 128)), dim3(256), 0, stream, a);
     DCV_LAUNCH_CHECK();
     return DCV_OK;
 }

@@ -1,4 +1,4 @@
-"""Runs only the attention entries at the headline shape (for rocprofv3 --pmc passes).  argv: repeats [fused|pair|all|ps]
+"""Runs only the attention entries at the headline shape (for rocprofv3 --pmc passes).  argv: repeats [pair|all|ps]
 (ps: the plain entries AND the pre-scaled-q entries on the same operand with its q part scaled — the counters of both forms side by side)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +21,4 @@ for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     hip.attn_fwd(qkv, o, lse, B, N, H, 64, 0.125)
     if what in ("pair", "all"):
         hip.attn_bwd(qkv, o, dO, lse, delta, dqkv, B, N, H, 64, 0.125)
-    if what in ("fused", "all"):
-        hip.attn_bwd_fused(qkv, o, dO, lse, dqkv, B, N, H, 64, 0.125)
 torch.cuda.synchronize()
