@@ -1039,6 +1039,8 @@ struct GemmTnArgs {
     float* part;       // deterministic mode: split s stores its partial tile to part[s * part_stride + p * Q + q] (and its bias partial to
     long part_stride;  // part[s * part_stride + P * Q + p]) with plain stores instead of adding atomically; det_reduce_kernel sums them
     long bias_off;     // gemm_tn384, deterministic mode: float offset in `part` of the bias partials [splits * tiles_q][P]
+    int mode;          // grouped launch only: 0 = 384 x 128 tiles; 1 = 384 x 256 tiles; 2 = 384 x 256 tiles of the TRANSPOSED product (Y and X exchanged by
+                       // the launcher: P, Q, ldy, ldx are the exchanged ones; dW / part / dbias keep the caller's layout: element (p, q) at q * P + p)
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
@@ -1186,8 +1188,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnArgs a) {
 constexpr int T3_BK = 32, T3_STAGES = DCV_T3_STAGES, T3_IMG = T3_BK * 256, T3_STAGE_BYTES = 4 * T3_IMG;  // 8 KB images, 32 KB stages
 
 // bid: the workgroup's logical id inside this product, in [0, tiles * splits), tile index fastest
-__device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid) {
-    __shared__ __attribute__((aligned(16))) char smem[T3_STAGES * T3_STAGE_BYTES];  // 128 KB: one workgroup per CU
+__device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid, char* smem) {  // smem: T3_STAGES * T3_STAGE_BYTES = 128 KB: one workgroup per CU
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave >> 1, wq = wave & 1;
@@ -1335,8 +1336,194 @@ __device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid) {
     }
 }
 
+#ifndef DCV_TN_WIDE_Q
+#define DCV_TN_WIDE_Q 0  // variant builds: bit 0: 384 x 256 tiles for products with Q % 256 == 0; bit 1: for the transposed product (measured: +3 % / +12 % SLOWER, profiles/r05_x5_*)
+#endif
+#if DCV_TN_WIDE_Q
+// ------------------------------------------------------------------------------------------------
+// gemm_tn384w (round 5): the same loop on a 384 (P) x 256 (Q) tile — 154 FLOP per operand byte pulled L2 -> LDS instead of 96.  Why: the 384 x 128 kernel
+// waits for operand delivery (MFMA busy 0.39; TCP_PENDING_STALL 49 % of the launch; 28.9 M 128-byte requests at 457 cycles each = 59 in flight per CU
+// by Little's law, 37 % of them compulsory HBM misses: profiles/r05_x5_*): the vector-memory path of a CU holds a fixed number of requests and every
+// one takes an HBM latency, so the lever is requests per FLOP.  8 waves as 4 (P) x 2 (Q), each 96 x 128 = 3 x 4 MFMA tiles (192 accumulators, two waves
+// per SIMD); a stage is five [32 rows][128 cols] images (40 KB), four stages = the whole LDS; five DMA pieces per wave and stage.
+// SWAP: the launcher exchanged Y and X (a product whose Q is 384 and whose P is a multiple of 256, e.g. fc1's 1536 x 384): the tile is one of the
+// transposed product, stored transposed (four consecutive p per lane: 16-byte stores at a row stride), and the bias gradient — the column sums of
+// the caller's Y — comes from the X images.
+constexpr int T3W_STAGES = 4, T3W_STAGE_BYTES = 5 * T3_IMG;  // 160 KB
+template <bool SWAP>
+__device__ __forceinline__ void tn384w_body(const GemmTnArgs& a, int bid, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wq = wave & 1;
+    const int h = lane >> 5, r32 = lane & 31, li = lane & 15, g1 = (lane >> 4) & 1;
+    const int tiles_q = a.Q / 256, tiles = tiles_q * (a.P / 384);
+    const int split = bid / tiles;
+    bid -= split * tiles;
+    const int tq = bid % tiles_q, tp = bid / tiles_q;
+    const int p0 = tp * 384, q0 = tq * 256;
+    const int m_begin = split * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    if (m_begin >= m_end) return;
+    const int nk = (m_end - m_begin + T3_BK - 1) / T3_BK;
+    const int last_valid = (m_end - m_begin) - (nk - 1) * T3_BK;
+
+    // DMA: piece p = 5 wave + j (j = 0..4) of the stage's 40: image p >> 3 (0-2: Y columns p0 + 128 image; 3, 4: X columns q0 + 128 (image - 3)), rows
+    // 4 (p & 7) .. + 3; lane -> row lane >> 4 of the four, physical chunk lane & 15 (the row's swizzle depends on row & 3 = lane >> 4 only)
+    const int lrow = lane >> 4, pc = lane & 15;
+    const int lcol = ((((pc >> 2) ^ (lrow & 3)) << 2) | (pc & 3)) * 8;
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const bf16_t* gsrc[5];
+    int gld[5], grow[5];
+    unsigned gdst[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int p = 5 * wave + j, img = p >> 3, rg = p & 7;
+        gsrc[j] = (img < 3 ? a.Y + p0 + 128 * img : a.X + q0 + 128 * (img - 3)) + lcol;
+        gld[j] = img < 3 ? a.ldy : a.ldx;
+        grow[j] = 4 * rg + lrow;
+        gdst[j] = img * T3_IMG + rg * 1024;
+    }
+#define T3W_ISSUE(kt_)                                                                                    \
+    {                                                                                                     \
+        const unsigned sb_ = smem_base + ((kt_) % T3W_STAGES) * T3W_STAGE_BYTES;                          \
+        _Pragma("unroll") for (int j = 0; j < 5; ++j) {                                                   \
+            const int m_ = min(m_begin + (kt_) * T3_BK + grow[j], m_end - 1); /* tail rows: zeroed in LDS below */ \
+            glds16(gsrc[j] + (size_t)m_ * gld[j], sb_ + gdst[j]);                                         \
+        }                                                                                                 \
+    }
+    for (int st = 0; st < T3W_STAGES - 1; ++st)
+        if (st < nk) T3W_ISSUE(st)
+
+    f32x16 acc[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int trow = 8 * h + (li >> 2);
+    int offA[3], offB[4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = 96 * wp + 32 * i + 16 * g1 + 4 * (li & 3);
+        offA[i] = (c >> 7) * T3_IMG + (c & 127);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 128 * wq + 32 * j + 16 * g1 + 4 * (li & 3);
+        offB[j] = (3 + (c >> 7)) * T3_IMG + (c & 127);
+    }
+    auto tr_off = [](int imgcol, int row) {
+        const int base = imgcol & ~127, col = imgcol & 127;
+        return base + lds128_off(row, col);
+    };
+
+    // bias gradient = column sums of the caller's Y: !SWAP: the three Y images (48 column chunks x 10 row groups), paced over the tiles of a row
+    // as in tn384_body; SWAP: the two X images (32 chunks x 16 row groups), by the first tile row only (every tile row sees the same X columns)
+    const bool do_bias = (a.dbias != nullptr) && (!SWAP || tp == 0);
+    constexpr int BCH = SWAP ? 32 : 48, BRG = SWAP ? 16 : 10;
+    const int bch = tid % BCH, brg = tid / BCH;
+    float bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int rem = nk - 1 - kt;  // younger stages in flight: min(rem, 2), 5 DMA pieces per wave each
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + T3W_STAGES - 1 < nk) T3W_ISSUE(kt + T3W_STAGES - 1)
+        char* st = smem + (kt % T3W_STAGES) * T3W_STAGE_BYTES;
+        if (kt == nk - 1 && last_valid < T3_BK) {  // ragged end of the reduction: rows that do not exist must contribute 0
+            const int nbad = T3_BK - last_valid;
+            for (int idx = tid; idx < nbad * 80; idx += 512) {
+                const int r = last_valid + idx / 80, im = (idx % 80) >> 4, ch = idx & 15;
+                lds_write128(st, im * T3_IMG + r * 256 + ch * 16, make_uint4(0, 0, 0, 0));
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row0 = 16 * ks + trow;
+            bf16x8 af[3], bf[4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) af[i] = join4(lds_tr_read(st, tr_off(offA[i], row0)), lds_tr_read(st, tr_off(offA[i], row0 + 4)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = join4(lds_tr_read(st, tr_off(offB[j], row0)), lds_tr_read(st, tr_off(offB[j], row0 + 4)));
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+        }
+        if (do_bias && (SWAP || (kt % tiles_q) == tq) && brg < BRG) {
+            const int im = (SWAP ? 3 : 0) + (bch >> 4), ci = bch & 15;
+            for (int r = brg; r < T3_BK; r += BRG) {
+                const int pcx = ((((ci >> 2) ^ (r & 3)) << 2) | (ci & 3));
+                const uint4 v = lds_read128(st, im * T3_IMG + r * 256 + pcx * 16);
+                bs[0] += __uint_as_float(v.x << 16); bs[1] += __uint_as_float(v.x & 0xffff0000u);
+                bs[2] += __uint_as_float(v.y << 16); bs[3] += __uint_as_float(v.y & 0xffff0000u);
+                bs[4] += __uint_as_float(v.z << 16); bs[5] += __uint_as_float(v.z & 0xffff0000u);
+                bs[6] += __uint_as_float(v.w << 16); bs[7] += __uint_as_float(v.w & 0xffff0000u);
+            }
+        }
+    }
+#undef T3W_ISSUE
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + wq * 128 + j * 32 + r32;
+            if constexpr (SWAP) {  // caller's layout: row q (its P index), column p (its Q index, a.P of them); registers 4g .. 4g + 3 = four consecutive p
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int p = p0 + wp * 96 + i * 32 + 8 * g + 4 * h;
+                    const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    if (a.part) {
+                        *reinterpret_cast<f32x4*>(a.part + (size_t)split * a.part_stride + (size_t)q * a.P + p) = v;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(a.dW + (size_t)q * a.lddw + p + e, v[e]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = p0 + wp * 96 + i * 32 + acc_row(r, h);
+                    if (a.part) a.part[(size_t)split * a.part_stride + (size_t)p * a.Q + q] = acc[i][j][r];
+                    else atomicAdd(a.dW + (size_t)p * a.lddw + q, acc[i][j][r]);
+                }
+            }
+        }
+    if (a.dbias != nullptr) {  // (uniform over the workgroup)
+        __syncthreads();  // all stage reads are done: reuse the ring for the partial sums
+        float* red = reinterpret_cast<float*>(smem);
+        if (do_bias && brg < BRG) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(brg * BCH + bch) * 8 + e] = bs[e];
+        }
+        __syncthreads();
+        if (do_bias && tid < BCH * 8) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < BRG; ++g) sum += red[g * BCH * 8 + tid];
+            if constexpr (SWAP) {  // bias index = the caller's P index = this product's Q index: one row of Q floats per split
+                if (a.part) a.part[a.bias_off + (size_t)split * a.Q + q0 + tid] = sum;
+                else atomicAdd(a.dbias + q0 + tid, sum);
+            } else {
+                if (a.part) a.part[a.bias_off + ((size_t)split * tiles_q + tq) * a.P + p0 + tid] = sum;
+                else atomicAdd(a.dbias + p0 + tid, sum);
+            }
+        }
+    }
+}
+
+#endif  // DCV_TN_WIDE_Q
+
 __global__ __launch_bounds__(512) void gemm_tn384_kernel(GemmTnArgs a) {
-    tn384_body(a, xcd_remap(blockIdx.x, (a.Q / 128) * (a.P / 384) * a.splits));
+    __shared__ __attribute__((aligned(16))) char smem[T3_STAGES * T3_STAGE_BYTES];  // 128 KB: one workgroup per CU
+    tn384_body(a, xcd_remap(blockIdx.x, (a.Q / 128) * (a.P / 384) * a.splits), smem);
 }
 
 // Several weight-gradient products over the SAME token rows in one launch (a block's fc2 / fc1 / proj / qkv gradients: 36 tiles).  The CUs are
@@ -1349,11 +1536,21 @@ struct GemmTnGroup {
     GemmTnArgs d[TN_GROUP_MAX];
 };
 __global__ __launch_bounds__(512) void gemm_tn384_group_kernel(GemmTnGroup g) {
+#if DCV_TN_WIDE_Q
+    __shared__ __attribute__((aligned(16))) char smem[T3W_STAGES * T3W_STAGE_BYTES];  // 160 KB (the 384 x 128 products use 128 KB of it)
+    static_assert(T3W_STAGES * T3W_STAGE_BYTES >= T3_STAGES * T3_STAGE_BYTES, "ring sizes");
+#else
+    __shared__ __attribute__((aligned(16))) char smem[T3_STAGES * T3_STAGE_BYTES];  // 128 KB: one workgroup per CU
+#endif
     const int id = xcd_remap(blockIdx.x, g.start[g.n]);
     int i = 0;
     while (i + 1 < g.n && id >= g.start[i + 1]) ++i;
     const GemmTnArgs a = g.d[i];
-    tn384_body(a, id - g.start[i]);
+#if DCV_TN_WIDE_Q
+    if (a.mode == 1) return tn384w_body<false>(a, id - g.start[i], smem);
+    if (a.mode == 2) return tn384w_body<true>(a, id - g.start[i], smem);
+#endif
+    tn384_body(a, id - g.start[i], smem);
 }
 
 }  // namespace
@@ -1552,7 +1749,7 @@ static int tn_launch(const void* Y, int ldy, const void* X, int ldx, int M, int 
         if (((uintptr_t)ws & 15) || (lddw % 4) || ((uintptr_t)dW & 15) || (dbias && ((uintptr_t)dbias & 15))) return DCV_ERR_ALIGN;
         if (ws_floats < need) return DCV_ERR_SHAPE;
     }
-    GemmTnArgs a{(const bf16_t*)Y, ldy, (const bf16_t*)X, ldx, M, P, Q, dW, lddw, dbias, mps, splits, ws, stride, bias_off};
+    GemmTnArgs a{(const bf16_t*)Y, ldy, (const bf16_t*)X, ldx, M, P, Q, dW, lddw, dbias, mps, splits, ws, stride, bias_off, 0};
     if (pick == DCV_TILE_WIDE) {
         hipLaunchKernelGGL(gemm_tn384_kernel, dim3((P / 384) * (Q / 128) * splits), dim3(512), 0, (hipStream_t)stream, a);
     } else {
@@ -1592,58 +1789,84 @@ extern "C" int dcv_gemm_tn_acc_det(const void* Y, int ldy, const void* X, int ld
 }
 
 // ---- grouped form (include/dcv.h: dcv_tn_item) --------------------------------------------------------------------------------------------
-static int tn_group_plan(const dcv_tn_item* it, int n, int M, int cus, int& splits, int& mps, long* off, long& need) {
+// Per item: the tile form (0: 384 x 128; 1: 384 x 256; 2: 384 x 256 of the transposed product), its splits over the token rows and rows per split.  A
+// 384 x 256 tile is two units of work, so its products get twice the splits of the 384 x 128 ones: every workgroup of the launch does the same FLOPs.
+struct TnGroupPlan {
+    int mode[TN_GROUP_MAX], splits[TN_GROUP_MAX], mps[TN_GROUP_MAX], tiles[TN_GROUP_MAX];
+    long off[TN_GROUP_MAX];
+    long need;
+};
+static int tn_group_plan(const dcv_tn_item* it, int n, int M, int cus, TnGroupPlan& pl) {
     if (!it) return DCV_ERR_NULL;
     if (n < 1 || n > TN_GROUP_MAX || M <= 0) return DCV_ERR_SHAPE;
-    int tiles = 0;
+    int units = 0;
     for (int i = 0; i < n; ++i) {
         if (!it[i].Y || !it[i].X || !it[i].dW) return DCV_ERR_NULL;
         if (it[i].P <= 0 || it[i].Q <= 0 || (it[i].P % 384) || (it[i].Q % 128)) return DCV_ERR_UNSUPPORTED;
         if ((it[i].ldy % 8) || (it[i].ldx % 8) || ((uintptr_t)it[i].Y & 15) || ((uintptr_t)it[i].X & 15)) return DCV_ERR_ALIGN;
-        tiles += (it[i].P / 384) * (it[i].Q / 128);
+        const int P = it[i].P, Q = it[i].Q;
+        if ((DCV_TN_WIDE_Q & 1) && (Q % 256) == 0) {
+            pl.mode[i] = 1;
+            pl.tiles[i] = (P / 384) * (Q / 256);
+        } else if ((DCV_TN_WIDE_Q & 2) && (Q % 384) == 0 && (P % 256) == 0) {
+            pl.mode[i] = 2;
+            pl.tiles[i] = (Q / 384) * (P / 256);
+        } else {
+            pl.mode[i] = 0;
+            pl.tiles[i] = (P / 384) * (Q / 128);
+        }
+        units += pl.tiles[i] * (pl.mode[i] ? 2 : 1);
     }
-    if (tiles > cus) return DCV_ERR_UNSUPPORTED;  // more than one resident round: call the products one by one
-    splits = cus / tiles;
+    if (units > cus) return DCV_ERR_UNSUPPORTED;  // more than one resident round: call the products one by one
+    const int base = cus / units;
     const int max3 = (M + T3_BK - 1) / T3_BK;
-    if (splits > max3) splits = max3;
-    mps = ((M + splits - 1) / splits + T3_BK - 1) / T3_BK * T3_BK;
-    splits = (M + mps - 1) / mps;
-    need = 0;
-    for (int i = 0; i < n; ++i) {  // per item: [splits][P * Q] partial tiles, then [splits * tiles_q][P] bias partials
-        off[i] = need;
-        need += (long)splits * it[i].P * it[i].Q + (long)splits * (it[i].Q / 128) * it[i].P;
+    pl.need = 0;
+    for (int i = 0; i < n; ++i) {
+        int sp = base * (pl.mode[i] ? 2 : 1);
+        if (sp > max3) sp = max3;
+        const int mps = ((M + sp - 1) / sp + T3_BK - 1) / T3_BK * T3_BK;
+        pl.mps[i] = mps;
+        pl.splits[i] = (M + mps - 1) / mps;
+        // per item: [splits][P * Q] partial tiles (the caller's layout), then the bias partials: [splits * tiles_q][P], or [splits][P] for the transposed form
+        pl.off[i] = pl.need;
+        const int bias_rows = pl.mode[i] == 2 ? pl.splits[i] : pl.splits[i] * (it[i].Q / (pl.mode[i] == 1 ? 256 : 128));
+        pl.need += (long)pl.splits[i] * it[i].P * it[i].Q + (long)bias_rows * it[i].P;
     }
     return DCV_OK;
 }
 
 extern "C" long dcv_gemm_tn_group_ws_floats(const dcv_tn_item* items, int n, int M) {
-    int splits, mps;
-    long off[TN_GROUP_MAX], need;
-    const int rc = tn_group_plan(items, n, M, dcv_cu_count(), splits, mps, off, need);
-    return rc ? rc : need;
+    TnGroupPlan pl;
+    const int rc = tn_group_plan(items, n, M, dcv_cu_count(), pl);
+    return rc ? rc : pl.need;
 }
 
 extern "C" int dcv_gemm_tn_group(const dcv_tn_item* items, int n, int M, float* ws, long ws_floats, void* stream) {
-    int splits, mps;
-    long off[TN_GROUP_MAX], need;
-    const int rc = tn_group_plan(items, n, M, dcv_cu_count(), splits, mps, off, need);
+    TnGroupPlan pl;
+    const int rc = tn_group_plan(items, n, M, dcv_cu_count(), pl);
     if (rc) return rc;
     if (ws) {
         if ((uintptr_t)ws & 15) return DCV_ERR_ALIGN;
-        if (ws_floats < need) return DCV_ERR_SHAPE;
-        for (int i = 0; i < n; ++i)
-            if ((items[i].lddw % 4) || ((uintptr_t)items[i].dW & 15) || (items[i].dbias && ((uintptr_t)items[i].dbias & 15))) return DCV_ERR_ALIGN;
+        if (ws_floats < pl.need) return DCV_ERR_SHAPE;
     }
+    for (int i = 0; i < n; ++i)
+        if ((items[i].lddw % 4) || ((uintptr_t)items[i].dW & 15) || (items[i].dbias && ((uintptr_t)items[i].dbias & 15))) {
+            if (ws || pl.mode[i] == 2) return DCV_ERR_ALIGN;
+        }
     GemmTnGroup g;
     g.n = n;
     int id = 0;
     for (int i = 0; i < n; ++i) {
         const dcv_tn_item& t = items[i];
         g.start[i] = id;
-        id += (t.P / 384) * (t.Q / 128) * splits;
+        id += pl.tiles[i] * pl.splits[i];
         const long stride = (long)t.P * t.Q;
-        g.d[i] = GemmTnArgs{(const bf16_t*)t.Y, t.ldy, (const bf16_t*)t.X, t.ldx, M, t.P, t.Q, t.dW, t.lddw, t.dbias, mps, splits,
-                            ws ? ws + off[i] : nullptr, stride, stride * splits};
+        if (pl.mode[i] == 2)  // the transposed product: operands exchanged; outputs keep the caller's layout
+            g.d[i] = GemmTnArgs{(const bf16_t*)t.X, t.ldx, (const bf16_t*)t.Y, t.ldy, M, t.Q, t.P, t.dW, t.lddw, t.dbias, pl.mps[i], pl.splits[i],
+                                ws ? ws + pl.off[i] : nullptr, stride, stride * pl.splits[i], 2};
+        else
+            g.d[i] = GemmTnArgs{(const bf16_t*)t.Y, t.ldy, (const bf16_t*)t.X, t.ldx, M, t.P, t.Q, t.dW, t.lddw, t.dbias, pl.mps[i], pl.splits[i],
+                                ws ? ws + pl.off[i] : nullptr, stride, stride * pl.splits[i], pl.mode[i]};
     }
     g.start[n] = id;
     for (int i = n + 1; i <= TN_GROUP_MAX; ++i) g.start[i] = id;
@@ -1656,9 +1879,10 @@ extern "C" int dcv_gemm_tn_group(const dcv_tn_item* items, int n, int M, float* 
         for (int i = 0; i < n; ++i) {
             const dcv_tn_item& t = items[i];
             const long stride = (long)t.P * t.Q;
-            float* w = ws + off[i];
-            if (!det_jobs_add(jb, w, splits, stride, t.dW, stride, t.Q, t.lddw)) return DCV_ERR_ALIGN;
-            if (t.dbias && !det_jobs_add(jb, w + stride * splits, splits * (t.Q / 128), t.P, t.dbias, t.P, t.P, t.P)) return DCV_ERR_ALIGN;
+            float* w = ws + pl.off[i];
+            if (!det_jobs_add(jb, w, pl.splits[i], stride, t.dW, stride, t.Q, t.lddw)) return DCV_ERR_ALIGN;
+            const int bias_rows = pl.mode[i] == 2 ? pl.splits[i] : pl.splits[i] * (t.Q / (pl.mode[i] == 1 ? 256 : 128));
+            if (t.dbias && !det_jobs_add(jb, w + stride * pl.splits[i], bias_rows, t.P, t.dbias, t.P, t.P, t.P)) return DCV_ERR_ALIGN;
         }
         if (!det_reduce_multi(jb, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
     }
