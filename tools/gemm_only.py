@@ -13,6 +13,7 @@ CASES = [("nt qkv      N1152 K384  bias", "nt", A, 3 * D, hip.EPI_BIAS_BF16), ("
          ("nt gelu-bwd N1536 K384", "nt", A, 4 * D, hip.EPI_GELU_BWD_BF16), ("nt dgrad    N384  K1536 plain", "nt", A4, D, hip.EPI_PLAIN_BF16),
          ("nt dgrad    N384  K1152 plain", "nt", A3, D, hip.EPI_PLAIN_BF16), ("nt dgrad    N384  K384  plain", "nt", A, D, hip.EPI_PLAIN_BF16),
          ("nt fc2      N384  K1536 bias+resid", "nt", A4, D, hip.EPI_BIAS_RESID_F32), ("nt proj     N384  K384  bias+resid", "nt", A, D, hip.EPI_BIAS_RESID_F32),
+         ("nt fc2      N384  K1536 bias+resid+LN", "ntln", A4, D, None), ("nt proj     N384  K384  bias+resid+LN", "ntln", A, D, None),
          ("tn wgrad    P1152 Q384", "tn", A3, A, None), ("tn wgrad    P1536 Q384", "tn", A4, A, None), ("tn wgrad    P384  Q1536", "tn", A, A4, None),
          ("tn wgrad    P384  Q384", "tn", A, A, None), ("tn group    fc2+fc1+proj+qkv", "tng", None, None, None)]
 if __name__ == "__main__":
@@ -28,6 +29,15 @@ if __name__ == "__main__":
             torch.cuda.synchronize()
             for _ in range(reps):
                 hip.gemm_nt(a, W, epi, out, bias=bias, out2=out2, aux=aux)
+        elif kind == "ntln":  # the residual GEMMs with the following LayerNorm in the epilogue (dcv_gemm_nt_resid_ln, gemm_nt384_kernel<6>)
+            N, K = n_or_x, a.shape[1]
+            W = (torch.randn(N, K, device="cuda") * 0.05).to(bf)
+            bias = torch.zeros(N, device="cuda"); resid = torch.randn(M, N, device="cuda"); x_out = torch.empty(M, N, device="cuda")
+            gamma = torch.ones(N, device="cuda"); beta = torch.zeros(N, device="cuda"); u_out = torch.empty(M, N, dtype=bf, device="cuda")
+            mean = torch.empty(M, device="cuda"); rstd = torch.empty(M, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(reps):
+                hip.gemm_nt_resid_ln(a, W, bias, resid, x_out, gamma, beta, 1e-6, u_out, mean, rstd)
         elif kind == "tng":  # a block's four weight gradients in one launch (dcv_gemm_tn_group)
             prods = [(A, A4), (A4, A), (A, A), (A3, A)]
             outs = [(torch.zeros(Y.shape[1], X.shape[1], device="cuda"), torch.zeros(Y.shape[1], device="cuda")) for Y, X in prods]

@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 root = sys.argv[1]
 REPS = 3
 names = ["nt qkv N1152 K384 bias", "nt fc1 N1536 K384 bias+gelu", "nt gelu-bwd N1536 K384", "nt dgrad N384 K1536 plain", "nt dgrad N384 K1152 plain",
-         "nt dgrad N384 K384 plain", "nt fc2 N384 K1536 bias+resid", "nt proj N384 K384 bias+resid", "tn wgrad P1152 Q384", "tn wgrad P1536 Q384",
+         "nt dgrad N384 K384 plain", "nt fc2 N384 K1536 bias+resid", "nt proj N384 K384 bias+resid", "nt fc2 N384 K1536 bias+resid+LN", "nt proj N384 K384 bias+resid+LN", "tn wgrad P1152 Q384", "tn wgrad P1536 Q384",
          "tn wgrad P384 Q1536", "tn wgrad P384 Q384", "tn group fc2+fc1+proj+qkv"]
 shapes = ["M100416 N1152 K384", "M100416 N1536 K384", "M100416 N1536 K384", "M100416 N384 K1536", "M100416 N384 K1152", "M100416 N384 K384",
-          "M100416 N384 K1536", "M100416 N384 K384", "M100416 P1152 Q384", "M100416 P1536 Q384", "M100416 P384 Q1536", "M100416 P384 Q384", "M100416 384x1536+1536x384+384x384+1152x384"]
+          "M100416 N384 K1536", "M100416 N384 K384", "M100416 N384 K1536", "M100416 N384 K384", "M100416 P1152 Q384", "M100416 P1536 Q384", "M100416 P384 Q1536", "M100416 P384 Q384", "M100416 384x1536+1536x384+384x384+1152x384"]
 res = collections.OrderedDict((n, {}) for n in names)
 sym = {}
 for f in sorted(glob.glob(root + "/p*/**/*_results.db", recursive=True)):
