@@ -107,8 +107,8 @@ def pos_embed_for(pos_embed: Tensor, n_tokens_minus_cls: int, w_img: int, h_img:
     ow, oh = int(math.floor(g * sw)), int(math.floor(g * sh))
     assert ow == w0 and oh == h0  # :546
     # reference reshapes to (1, g, g, D) -> NCHW; first spatial axis gets scale sw, second sh
-    Ry = torch.from_numpy(bicubic_matrix_1d(g, ow, sw)).to(pos_embed.dtype)
-    Rx = torch.from_numpy(bicubic_matrix_1d(g, oh, sh)).to(pos_embed.dtype)
+    Ry = torch.from_numpy(bicubic_matrix_1d(g, ow, sw)).to(pos_embed)  # dtype AND device of the table (the checker may run on the device: tests)
+    Rx = torch.from_numpy(bicubic_matrix_1d(g, oh, sh)).to(pos_embed)
     grid = pos_embed[0, 1:].reshape(g, g, D)
     out = _BicubicResample.apply(grid, Ry, Rx).reshape(1, ow * oh, D)
     out = out.expand(nc, ow * oh, D).reshape(1, nc * ow * oh, D)  # :550 same tile per channel
@@ -124,7 +124,7 @@ def ortho_loss_dense(feat: Tensor, labels: Tensor, gamma_s: float, gamma_d: floa
     and boolean masks (models/loss_fn.py:24-59)."""
     f = F.normalize(feat, p=2, dim=-1)  # :33 (eps 1e-12)
     same = labels[:, None] == labels[None, :]  # :37
-    eye = torch.eye(labels.numel(), dtype=torch.bool)
+    eye = torch.eye(labels.numel(), dtype=torch.bool, device=feat.device)
     m_pos = (same & ~eye).to(feat.dtype)  # :40
     m_neg = (~same).to(feat.dtype)  # :41
     dots = f @ f.transpose(-2, -1)  # :42
@@ -223,7 +223,7 @@ def tokenise(sd: Dict[str, Tensor], x: Tensor, cfg, ch_ids: Sequence[int], idx: 
     C = len(idx)
     Y = patch_tokens(sd, xs, P)  # [B,T,D]
     n = Y.shape[1] // C
-    extra = torch.zeros((), dtype=Y.dtype)
+    extra = torch.zeros((), dtype=Y.dtype, device=Y.device)
     lam_o = cfg.get("ortho_loss_v1_lambda", 0) or 0
     lam_p = cfg.get("proxy_loss_lambda", 0) or 0
     if lam_o > 0:  # :378-389
@@ -231,14 +231,14 @@ def tokenise(sd: Dict[str, Tensor], x: Tensor, cfg, ch_ids: Sequence[int], idx: 
             Y, C, n, cfg["gamma_s"], cfg["gamma_d"], cfg["reverse_pos_pairs"], cfg["use_square"])
     if not cfg.get("use_channelvit_channels", True):  # :83-95, 121, 409: no channel_embed parameter, no channel offset on the tokens
         assert lam_p == 0, "the reference leaves channel_embed unbound in this mode: the proxy term cannot be evaluated"
-        E = torch.zeros(C, Y.shape[-1], dtype=Y.dtype)
+        E = torch.zeros(C, Y.shape[-1], dtype=Y.dtype, device=Y.device)
     else:
         E_all = sd["feature_extractor.patch_embed.channel_embed.weight"]
         E = E_all[list(ch_ids)] if channel_embed_rows is None else channel_embed_rows  # :122,136/212
     if lam_p > 0:  # :399-402
         Pr = sd["feature_extractor.patch_embed.channel_emb_proxies"][list(ch_ids)]
         s = math.sqrt(1.0 / cfg["temperature"])  # :60
-        extra = extra + lam_p * proxy_loss(Pr, E, torch.eye(C, dtype=Y.dtype), s)
+        extra = extra + lam_p * proxy_loss(Pr, E, torch.eye(C, dtype=Y.dtype, device=Y.device), s)
     Z = Y + E.repeat_interleave(n, dim=0)[None]  # :409-411 (token t = c*n + i)
     cls = sd["feature_extractor.cls_token"].expand(B, -1, -1)
     Z = torch.cat([cls, Z], dim=1)  # :561-562

