@@ -97,8 +97,117 @@ __global__ __launch_bounds__(THREADS) void probe(int iters, unsigned long long* 
     if (lane == 0) cyc[blockIdx.x * 16 + wave] = t1 - t0;
 }
 
+// mode 6 (round 5): mode 5's dependent bursts grown towards the attention forward loop one feature at a time — FEAT bit 0: the A operands
+// of the 8 MFMAs come from LDS at the loop's rate (4 ds_read_b128 + 8 ds_read_b64_tr_b16 per 8 MFMAs, swizzle-free conflict-free addresses); bit 1: one s_barrier per
+// two iterations (= per key tile) inside each four-wave workgroup; bit 2: four LDS-DMA pieces per wave and tile from an L2-resident buffer behind a counted vmcnt.
+// Workgroups of 256 threads; WPS = 1 / 2 / 3 of them per CU (LDS size), i.e. 1 / 2 / 3 waves per SIMD with INDEPENDENT barriers, as the real kernel runs.
+typedef __attribute__((ext_vector_type(4))) short s16x4v;
+template <int FEAT, int LDSKB>
+__global__ __launch_bounds__(256) void probe6(int iters, unsigned long long* cyc, float* sink, float seed, const char* gbuf) {
+    __shared__ __attribute__((aligned(16))) char lds[LDSKB * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 32 * 1024 / 4; i += 256) reinterpret_cast<float*>(lds)[i] = 0.001f * (i & 63);
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (lane + i)); b[i] = (__bf16)(0.002f * (lane - i)); }
+    f32x16 acc[4];
+    for (int u = 0; u < 4; ++u)
+        for (int i = 0; i < 16; ++i) acc[u][i] = seed * (u + i);
+    float f[8];
+    for (int i = 0; i < 8; ++i) f[i] = seed + 0.01f * (lane + i);
+    float c2 = 1e-7f;
+    const int rbase = (lane & 31) * 128 + ((lane >> 5) << 4);  // row reads: lane -> row, 16-byte chunk (conflict-free without a swizzle at this stride pattern is not the point: same instruction count)
+    const int tbase = ((lane >> 5) * 4 + ((lane & 15) >> 2)) * 128 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) void*)lds;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        const int so = (it & 1) * 16384;
+        if constexpr (FEAT & 4) {
+            if ((it & 1) == 0) {  // one tile = two iterations: four 1 KB pieces per wave, waited for one tile later
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
+        }
+        if constexpr (FEAT & 2) {
+            if ((it & 1) == 0) __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (FEAT & 4) {
+            if ((it & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const char* src = gbuf + ((size_t)((blockIdx.x * 4 + wave) & 255) * 4096 + j * 1024 + lane * 16);
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(lds_base + 32768 + (wave * 4 + j) * 1024) : "memory");
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if constexpr (FEAT & 1) {
+                bf16x8 af;
+                if (u < 4) {
+                    af = *reinterpret_cast<const bf16x8*>(lds + so + rbase + u * 4096 % 16384);
+                } else {
+                    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(lds + so + tbase + (u - 4) * 2048));
+                    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4v*)(lds + so + tbase + (u - 4) * 2048 + 1024));
+                    typedef short s16x8v __attribute__((ext_vector_type(8)));
+                    const s16x8v j8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    af = __builtin_bit_cast(bf16x8, j8);
+                }
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[u & 3]) : "v"(af), "v"(b));
+            } else {
+                MFMA(acc[u & 3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8 * 14; ++k) {  // the forward's mix: 28 v_exp + 84 v_fma per 8 MFMAs, every one reading an accumulator
+            if ((k % 8) < 2) VEXP(f[k & 7]);
+            else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(f[k & 7]) : "v"(acc[k & 3][(k >> 2) & 15]), "v"(c2));
+        }
+        unsigned bw[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(bw[i]) : "v"(f[2 * i]), "v"(f[2 * i + 1]));
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        const u32x4v bv = {bw[0], bw[1], bw[2], bw[3]};
+        b = __builtin_bit_cast(bf16x8, bv);
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int u = 0; u < 4; ++u)
+        for (int i = 0; i < 16; ++i) s += acc[u][i];
+    for (int i = 0; i < 8; ++i) s += f[i];
+    if (s == 0.12345f) sink[tid] = s;
+    if (lane == 0 && blockIdx.x < 256) cyc[blockIdx.x * 16 + wave] = t1 - t0;
+}
+
 static unsigned long long* d_cyc;
 static float* d_sink;
+static char* d_gbuf;
+
+template <int FEAT, int LDSKB>
+static void run6(const char* what, int wps) {
+    const int grid = 256 * wps, iters = 2000;
+    std::vector<unsigned long long> h(256 * 16);
+    hipMemset(d_cyc, 0, 256 * 16 * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL((probe6<FEAT, LDSKB>), dim3(grid), dim3(256), 0, 0, 200, d_cyc, d_sink, 1.0f, d_gbuf);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((probe6<FEAT, LDSKB>), dim3(grid), dim3(256), 0, 0, iters, d_cyc, d_sink, 1.0f, d_gbuf);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h.data(), d_cyc, 256 * 16 * 8, hipMemcpyDeviceToHost);
+    double c = 0;
+    for (int g = 0; g < 256; ++g)
+        for (int w = 0; w < 4; ++w) c += (double)h[g * 16 + w] / iters;
+    c /= 1024;
+    printf("%-96s %d wave(s)/SIMD  %8.1f cyc/iter per wave  (serial %5.0f overlap %5.0f)  %.2f GHz  %7.1f us\n", what, wps, c, wps * (256 + 560.0), wps * 560.0, c * iters / (ms * 1e6), ms * 1e3);
+}
 
 template <int MODE, int K, int E, int THREADS>
 static void run(const char* what, double model_serial, double model_overlap) {
@@ -170,5 +279,14 @@ int main() {
     run<5, 14, 2, 768>("  3 waves/SIMD, same", 3 * (256 + 560), 3 * 560.0);
     run<5, 7, 0, 512>("  2 waves/SIMD, 56 v_fma on the accumulators", 2 * (256 + 224), 2 * 256.0);
     run<5, 7, 0, 768>("  3 waves/SIMD, 56 v_fma on the accumulators", 3 * (256 + 224), 3 * 256.0);
+    hipMalloc(&d_gbuf, 256 * 4096);
+    hipMemset(d_gbuf, 0, 256 * 4096);
+    printf("## mode 6: mode 5 (dependent bursts, the forward's mix) grown towards the real loop; 256-thread workgroups, 1 / 2 / 3 per CU, barriers per workgroup\n");
+#define R6(F, what) run6<F, 100>(what, 1); run6<F, 64>(what, 2); run6<F, 48>(what, 3);
+    R6(0, "  registers only (= mode 5)");
+    R6(1, "  + A operands from LDS (4 ds_read_b128 + 8 ds_read_b64_tr_b16 per 8 MFMAs)");
+    R6(3, "  + one s_barrier per tile (two iterations) per workgroup");
+    R6(7, "  + four LDS-DMA pieces per wave and tile, counted vmcnt");
+    R6(6, "  barrier + DMA without the LDS operand reads");
     return 0;
 }
