@@ -36,7 +36,8 @@ def _stale(target, deps):
 #: lives in tools/probes/gemm_instrumented.hip (the shipped csrc/gemm.hip carries none of it: VERDICT r3 item 8)
 INSTRUMENTED = {"gemm.hip": os.path.join(HERE, "..", "tools", "probes", "gemm_instrumented.hip"),
                 "attn.hip": os.path.join(HERE, "..", "tools", "probes", "attn_instrumented.hip"),
-                "attn_bwd.hip": os.path.join(HERE, "..", "tools", "probes", "attn_bwd_instrumented.hip")}  # -DDCV_FABL=<mask>: forward-loop ablations
+                "attn_bwd.hip": os.path.join(HERE, "..", "tools", "probes", "attn_bwd_instrumented.hip"),
+                "attn_bwd3.hip": os.path.join(HERE, "..", "tools", "probes", "attn_bwd3_instrumented.hip")}  # -DDCV_K3_ABL=<mask>: timing-only ablations of the persistent dK/dV kernel  # -DDCV_FABL=<mask>: forward-loop ablations
 
 
 def build_variant(name: str, defines, verbose: bool = True, flags=(), instrumented=()) -> str:

@@ -1,3 +1,6 @@
+// DIAGNOSTIC TWIN of diverse_channel_vit_amd/csrc/attn_bwd3.hip (snapshot of round 5): the same kernel WITH the timing-only ablation switches (-DDCV_K3_ABL=<mask>, tools/attn3_fit.py;
+// results in profiles/r05_x3_*) and the cycle stamps (-DDCV_K3_STAMP; found useless in the persistent form: a pending s_memtime turns hipcc's counted lgkmcnt waits into lgkmcnt(0)).
+// Built in place of the product source by _build.build_variant(..., instrumented=("attn_bwd3.hip",)); never part of libdcv_hip.so.
 // Attention backward, dK / dV, third form (head_dim 64, pre-scaled q): ONE wave per SIMD owning the whole 512-entry register file, 64 keys per
 // wave, persistent workgroups (cdna guide, appendix B "Attention backward" and "4-wave, one-wave-per-SIMD, persistent structure": one workgroup =
 // 4 waves = 256 keys of one (batch, head); each wave keeps dK^T and dV^T of its 64 keys in accumulator registers while the workgroup sweeps the
@@ -29,10 +32,17 @@
 
 namespace {
 
+#ifndef DCV_K3_ABL
+#define DCV_K3_ABL 0  // timing-only ablations (tools/attn3_fit.py on variant builds): 1 no stores, 2 no K/V DMA, 4 no ring DMA inside items, 8 no wait / barrier per tile,
+#endif                 // 16 no vector fillers, 32 no LDS fragment reads in the steps, 64 no MFMAs
 constexpr int K3_KEYS = 256;  // keys per workgroup item
-constexpr int P3_STAGES = 5, P3_STAGE_BYTES = 16384 + 1024;  // stage: Q tile | dO tile | -LSE log2e [64] | -delta [64] | 512 B scratch
+constexpr int P3_STAGES = 5, P3_STAGE_BYTES = 16384 + 1024, P3_DMA = 5;  // stage: Q tile | dO tile | -LSE log2e [64] | -delta [64] | 512 B scratch
 constexpr int P3_R_BYTES = 16384;  // per-wave region R: next item's K tile | V tile (swizzled like a ring tile), then this item's dK | dV tiles
 
+#ifdef DCV_K3_STAMP  // diagnostic build only ((removed)): cycle stamps of wave 0 of every workgroup; never in the product library
+__device__ unsigned long long k3_stamps[1024 * 8];
+#define K3_NOW() __builtin_amdgcn_s_memtime()
+#endif
 // even step, gap g: which of the 16 row / statistics reads (load_rows index: 0-3 stl, 4-7 std_, 8-11 rq, 12-15 rdo) and which of the 8 transposed
 // reads go out.  A register is reloaded only after the MFMA that last read it: stl / std_ (C operands of MFMA 0 / 1) from gap 2, rq[ks] after
 // MFMA 2 ks, rdo[ks] after MFMA 2 ks + 1.
@@ -150,13 +160,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
             cursor_ptrs();
         }
     };
+#ifdef DCV_K3_STAMP
+    unsigned long long st_wait = 0, st_issue = 0, st_seam = 0, st_items = 0;
+    const unsigned long long st_entry = K3_NOW();
+#endif
     // Every second tile (even t): everything this wave has in flight has landed — the stages issued two tiles ago (t + 1, t + 2: tile t + 1 reads the rows of
     // t + 2), the trickled pieces — then, behind the barrier, everyone is done with the tiles before t and the ring is refilled up to stage
     // t + 4.  One barrier and one scalar prologue per TWO tiles: at one per tile they cost 470 cycles of a 2800-cycle tile (timing-only ablation).
     auto top = [&](int t) {
-        if (t != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // t = 0: the item's seam has drained
-        __builtin_amdgcn_s_barrier();
-        while (n_ahead < P3_STAGES && c_it.valid) advance();
+#ifdef DCV_K3_STAMP
+        unsigned long long s0 = 0, s1 = 0, s2 = 0;
+        if (DCV_K3_STAMP >= 2) s0 = K3_NOW();
+#endif
+        if (!(DCV_K3_ABL & 8)) {
+            if (t != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // t = 0: the item's seam has drained
+            __builtin_amdgcn_s_barrier();
+        }
+#ifdef DCV_K3_STAMP
+        if (DCV_K3_STAMP >= 2) s1 = K3_NOW();
+#endif
+        if (!(DCV_K3_ABL & 4))
+            while (n_ahead < P3_STAGES && c_it.valid) advance();
+#ifdef DCV_K3_STAMP
+        if (DCV_K3_STAMP >= 2) {
+            s2 = K3_NOW();
+            st_wait += s1 - s0;
+            st_issue += s2 - s1;
+        }
+#endif
     };
 
     const LaneOffs lo = lane_offs(lane);
@@ -184,6 +215,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
         const int key = min(it.key0 + row, a.N - 1);
         const unsigned voff = (unsigned)(((size_t)key * rs + (((lane & 7) ^ swz64(row)) << 3)) * 2);
         const bf16_t* kb_ = q_base(it) + D;
+        if (DCV_K3_ABL & 2) return;
         glds16s(kb_, voff, smemR + j * 1024);
         glds16s(kb_ + D, voff, smemR + 8192 + j * 1024);
     };
@@ -209,11 +241,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
         const int row = 8 * i + (lane >> 3);
         const int off = row * 128 + (((lane & 7) ^ swz64(row)) << 4);
         const uint4 v0 = lds_read128(sR, off), v1 = lds_read128(sR, 8192 + off);
+#if (DCV_K3_ABL & 1)  // timing-only ablation: no stores
+        asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w));
+#else
         if (it.key0 + row < a.key_hi) {
             bf16_t* const dst = a.dqkv + ((size_t)it.b * a.N + it.key0 + row) * rs + D + it.hh * 64 + (lane & 7) * 8;
             *reinterpret_cast<uint4*>(dst) = v0;
             *reinterpret_cast<uint4*>(dst + D) = v1;
         }
+#endif
     };
     auto load_rows = [&](int so, int qb, int i) {  // i = 0..15: one ds_read_b128 of the 16 that make (stl, std_, rq, rdo) of slice qb in stage so
         if (i < 4) {
@@ -249,10 +285,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
         bf16x4 half[2];
         float pv[16], dsv[16];
         unsigned pw[8], dw[8];  // packed P / dS pairs: word i of k-step ss = i >> 2
+        if (DCV_K3_ABL & 16)
+            for (int i = 0; i < 8; ++i) pw[i] = dw[i] = 0;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             // ---- the MFMA of gap g
-            if (g < 8) {
+            if (DCV_K3_ABL & 64) {
+            } else if (g < 8) {
                 const int ks = g >> 1;
                 if constexpr (J == 3 && decltype(LAST)::value) {
                     // no unit follows in this item
@@ -271,6 +310,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
             }
             // ---- fillers: the vector work of this unit, one element per gap; the multiply and the packing trail the exponential by one and two
             // gaps (a dependent instruction right behind a v_exp waits for its result: nothing else is there to issue with one wave per SIMD)
+            if (!(DCV_K3_ABL & 16)) {
             float p = __builtin_amdgcn_exp2f(sx[X][g]);
             if constexpr (decltype(MASKED)::value) {
                 if ((g & 3) + 8 * (g >> 2) >= lim) p = 0.f;
@@ -298,11 +338,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
                 P3_PIN(dw[6]);
                 P3_PIN(dw[7]);
             }
+            }
             // ---- ... and the LDS reads of the steps ahead.  Even step: the next slice's rows and statistics go out as soon as the MFMA that last read
             // each register has issued (tables below) — 13 and more gaps before their first use, so the burst of the four lockstepped waves
             // (64 ds_read_b128 within ~300 cycles: the LDS array is busy for 256 of them) queues without anybody waiting for it — and k-step 0 of this
             // slice's transposed fragments (first used in the next step's second half) fills the rest.  Odd step: k-step 1 (used from MFMA 12 on).
-            if ((J & 1) == 0) {
+            if (DCV_K3_ABL & 32) {
+            } else if ((J & 1) == 0) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int i = P3_ROWS_AT[g][e];
@@ -392,6 +434,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
     if (cur.valid && cur.key0 < a.key_hi)
         for (int j = 0; j < 8; ++j) kv_dma_pair(cur, j);
     for (int k = 0; cur.valid; ++k) {
+#ifdef DCV_K3_STAMP
+        const unsigned long long q0 = K3_NOW();
+#endif
         const bool active = cur.key0 < a.key_hi;  // a wave without a single valid key only keeps the ring going
         nxt = item_of(k + 1);
         nxt_active = nxt.valid && nxt.key0 < a.key_hi;
@@ -442,6 +487,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
             P3_FENCE();
         }
+#ifdef DCV_K3_STAMP
+        const unsigned long long q1 = K3_NOW();
+        st_seam += q1 - q0;
+        ++st_items;
+#endif
         if (active) {
             for (int t = 0; t < nt - 1; ++t) tile(No{}, t);
             tile(Yes{}, nt - 1);
@@ -473,9 +523,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
         acc_to_R();
         for (int i = 0; i < 8; ++i) store_pair(prev, i);
     }
+#ifdef DCV_K3_STAMP
+    if (tid == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = k3_stamps + (size_t)blockIdx.x * 8;
+        o[0] = st_entry; o[1] = st_seam; o[2] = st_items; o[3] = K3_NOW(); o[4] = st_wait; o[5] = st_issue; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = nt;
+    }
+#endif
 }
 
 }  // namespace
+#ifdef DCV_K3_STAMP
+extern "C" int dcv_k3_stamps(void* host_dst, size_t bytes) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(k3_stamps), bytes < sizeof(k3_stamps) ? bytes : sizeof(k3_stamps)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 static int k3_cus() {
     static int n = 0;
