@@ -16,6 +16,10 @@
 //                   are bitwise reproducible.
 #include "attn_common.hpp"
 
+#ifndef DCV_FWD_LSUM_MFMA
+#define DCV_FWD_LSUM_MFMA 0  // 1 (variant builds): measured +1 % SLOWER (profiles/r05_x7_*)
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -93,6 +97,13 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
     constexpr float FWD_RESCALE_LOG2 = 8.f;
     f32x16 minit;
     zero_acc(minit);
+    // DCV_FWD_LSUM_MFMA (pre-scaled-q form): the softmax denominator from the matrix pipe — one more MFMA per 32 x 16 block of P with an all-ones A operand, whose
+    // every output row is the column sum of P — instead of 32 v_add per tile and wave; the sum is then over the bf16 P the numerator uses
+    f32x16 lacc;
+    zero_acc(lacc);
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
     // COMPUTE = false: a wave without a valid query row only keeps the ring going; separate loops, not a branch in the loop
     // (attn_bwd.hip: the branch made the accumulators loop-carried phis resolved with register copies)
@@ -141,6 +152,10 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
                 // t = 0: l and O are still zero, and exp2(-d) is +inf when every score of the first tile lies below -127 (log2 units): 0 * inf = NaN
                 const float alpha = (t == 0) ? 0.f : __builtin_amdgcn_exp2f(-d);
                 l *= alpha;
+                if (DCV_FWD_LSUM_MFMA) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+                }
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -159,7 +174,7 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const float p = __builtin_amdgcn_exp2f(s[kb][r]);
                     s[kb][r] = p;
-                    rsum += p;
+                    if (!DCV_FWD_LSUM_MFMA) rsum += p;
                 }
         } else {
         float mx = m;
@@ -201,6 +216,7 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
                     o[dt] = mfma32(join4(lds_tr_read(sKV, co[dt][0] + cc), lds_tr_read(sKV, co[dt][1] + cc)), pf, o[dt]);
+                if (PS && DCV_FWD_LSUM_MFMA) lacc = mfma32(ones, pf, lacc);  // every row of the product = the column sums of P: the softmax denominator
             }
     };
     using No = std::integral_constant<bool, false>;
@@ -221,7 +237,8 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
         if (nfull < nt) tile(Yes{}, No{}, nfull, slot);
     }
 
-    l += __shfl_xor(l, 32, 64);
+    if (PS && DCV_FWD_LSUM_MFMA) l = lacc[0];  // (all 32 rows equal; both lane halves hold the full sum over the keys)
+    else l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
     if (q < a.Nq) {
         bf16_t* op = a.o + ((size_t)b * a.N + q) * D + hh * 64;
