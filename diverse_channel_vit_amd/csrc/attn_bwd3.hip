@@ -417,12 +417,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
                 }
             asm volatile("s_nop 1"  // as in kv_frags: the v_accvgpr_writes of the zeroing sit above this statement, not in front of an asm MFMA
                          : "+a"(dk[0][0]), "+a"(dk[0][1]), "+a"(dk[1][0]), "+a"(dk[1][1]), "+a"(dv[0][0]), "+a"(dv[0][1]), "+a"(dv[1][0]), "+a"(dv[1][1]));
+            // Empty neighbours: the first step's dV / dK MFMAs (unit -1) add zero.  The zeros are PINNED into registers here: left as constants, hipcc may
+            // rematerialise them with v_mov directly in front of the asm MFMA that reads them — no hazard padding towards asm — and the MFMA then reads the
+            // registers' old contents (seen in a variant of this kernel: NaN in dV of key block 1; profiles/r05_x3, item 9).
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    pf[i][j] = dsf[i][j] = tr1[i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));  // the first step's dV / dK MFMAs (unit -1) add zero
+                    pf[i][j] = dsf[i][j] = tr1[i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));
                     tr0[1][i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));
+                    asm volatile("" : "+v"(pf[i][j]), "+v"(dsf[i][j]), "+v"(tr1[i][j]), "+v"(tr0[1][i][j]));
                 }
             // prologue: the rows of slice (0, 0), S' and dP' of unit 0
             const int so = slot * P3_STAGE_BYTES;
