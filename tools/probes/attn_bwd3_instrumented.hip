@@ -468,6 +468,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv3p_kernel(AttnArgs a) {
                 for (int j = 0; j < 2; ++j) {
                     pf[i][j] = dsf[i][j] = tr1[i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));  // the first step's dV / dK MFMAs (unit -1) add zero
                     tr0[1][i][j] = as_bf16x8(make_uint4(0, 0, 0, 0));
+                    asm volatile("" : "+v"(pf[i][j]), "+v"(dsf[i][j]), "+v"(tr1[i][j]), "+v"(tr0[1][i][j]));  // pinned: see the product source
                 }
             // prologue: the rows of slice (0, 0), S' and dP' of unit 0
             const int so = slot * P3_STAGE_BYTES;
