@@ -439,6 +439,13 @@ def main():
                 roof["traffic"] = round(v["read_bytes_per_launch"] + v["written_bytes_per_launch"])
                 roof["traffic_unit"] = "bytes/launch (HBM, PMC: 2 x FETCH_SIZE + WRITE_SIZE)"
                 roof["traffic_source"] = "profiles/" + os.path.basename(pmc_path)
+                if dominant == "attn_bwd_dkdv3p_kernel":
+                    # one dcv_attn_bwd_dkdv_rows_ps call = the persistent kernel + the second form's launch for the key remainder (N = 1569: 33 keys); the events
+                    # bracket the call, rocprofv3 lists the two symbols separately
+                    tails = [v for k, v in pmc.items() if k.startswith("attn_bwd_dkdv2_kernel<true, true>")]
+                    if tails:
+                        roof["traffic"] += round(tails[0]["read_bytes_per_launch"] + tails[0]["written_bytes_per_launch"])
+                    roof["launch_includes"] = "attn_bwd_dkdv3p_kernel + attn_bwd_dkdv2_kernel<true, true> (key remainder) of one C-ABI call; rocprofv3 reports them as two symbols"
         # ---- the roofline that binds the STEP: executed FLOPs at the dense bf16 peak against HBM bytes (PMC, whole step)
         # at the HBM peak.  The PMC passes cover `steps` whole steps of this command (tools/pmc_traffic.sh: 2 timed + 1 warm-up).
         step_roof = None
