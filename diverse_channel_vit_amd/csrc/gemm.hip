@@ -1337,7 +1337,7 @@ __device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid, char* s
 }
 
 #ifndef DCV_TN_WIDE_Q
-#define DCV_TN_WIDE_Q 0  // variant builds: bit 0: 384 x 256 tiles for products with Q % 256 == 0; bit 1: for the transposed product (measured: +3 % / +12 % SLOWER, profiles/r05_x5_*)
+#define DCV_TN_WIDE_Q 0  // variant builds: bit 0: 384 x 256 tiles for products with Q % 256 == 0; bit 1: for the transposed product (measured: +3 % / +12 % SLOWER, profiles/r05_x5_*); bit 2: 384 x 192 tiles for Q % 192 == 0
 #endif
 #if DCV_TN_WIDE_Q
 // ------------------------------------------------------------------------------------------------
@@ -1350,17 +1350,21 @@ __device__ __forceinline__ void tn384_body(const GemmTnArgs& a, int bid, char* s
 // transposed product, stored transposed (four consecutive p per lane: 16-byte stores at a row stride), and the bias gradient — the column sums of
 // the caller's Y — comes from the X images.
 constexpr int T3W_STAGES = 4, T3W_STAGE_BYTES = 5 * T3_IMG;  // 160 KB
-template <bool SWAP>
+// NJ = 3: a 384 x 192 tile on the same five images (waves 96 x 96 = 3 x 3 MFMA tiles, 144 accumulators; 128 FLOP per operand byte): every product of the model has
+// Q % 192 == 0.  The fifth image then holds X columns 128-191 only; its DMA lanes whose slot lies in the unused half fetch the used half's lines again (no new request).
+template <bool SWAP, int NJ = 4>
 __device__ __forceinline__ void tn384w_body(const GemmTnArgs& a, int bid, char* smem) {
+    static_assert(NJ == 4 || (NJ == 3 && !SWAP), "tile widths");
+    constexpr int QT = 64 * NJ;  // tile width
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave >> 1, wq = wave & 1;
     const int h = lane >> 5, r32 = lane & 31, li = lane & 15, g1 = (lane >> 4) & 1;
-    const int tiles_q = a.Q / 256, tiles = tiles_q * (a.P / 384);
+    const int tiles_q = a.Q / QT, tiles = tiles_q * (a.P / 384);
     const int split = bid / tiles;
     bid -= split * tiles;
     const int tq = bid % tiles_q, tp = bid / tiles_q;
-    const int p0 = tp * 384, q0 = tq * 256;
+    const int p0 = tp * 384, q0 = tq * QT;
     const int m_begin = split * a.m_per_split;
     const int m_end = min(a.M, m_begin + a.m_per_split);
     if (m_begin >= m_end) return;
@@ -1378,7 +1382,7 @@ __device__ __forceinline__ void tn384w_body(const GemmTnArgs& a, int bid, char* 
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int p = 5 * wave + j, img = p >> 3, rg = p & 7;
-        gsrc[j] = (img < 3 ? a.Y + p0 + 128 * img : a.X + q0 + 128 * (img - 3)) + lcol;
+        gsrc[j] = (img < 3 ? a.Y + p0 + 128 * img : a.X + q0 + 128 * (img - 3)) + ((NJ == 3 && img == 4) ? (lcol & 63) : lcol);
         gld[j] = img < 3 ? a.ldy : a.ldx;
         grow[j] = 4 * rg + lrow;
         gdst[j] = img * T3_IMG + rg * 1024;
@@ -1394,24 +1398,24 @@ __device__ __forceinline__ void tn384w_body(const GemmTnArgs& a, int bid, char* 
     for (int st = 0; st < T3W_STAGES - 1; ++st)
         if (st < nk) T3W_ISSUE(st)
 
-    f32x16 acc[3][4];
+    f32x16 acc[3][NJ];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int trow = 8 * h + (li >> 2);
-    int offA[3], offB[4];
+    int offA[3], offB[NJ];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int c = 96 * wp + 32 * i + 16 * g1 + 4 * (li & 3);
         offA[i] = (c >> 7) * T3_IMG + (c & 127);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = 128 * wq + 32 * j + 16 * g1 + 4 * (li & 3);
+    for (int j = 0; j < NJ; ++j) {
+        const int c = 32 * NJ * wq + 32 * j + 16 * g1 + 4 * (li & 3);
         offB[j] = (3 + (c >> 7)) * T3_IMG + (c & 127);
     }
     auto tr_off = [](int imgcol, int row) {
@@ -1447,15 +1451,15 @@ __device__ __forceinline__ void tn384w_body(const GemmTnArgs& a, int bid, char* 
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int row0 = 16 * ks + trow;
-            bf16x8 af[3], bf[4];
+            bf16x8 af[3], bf[NJ];
 #pragma unroll
             for (int i = 0; i < 3; ++i) af[i] = join4(lds_tr_read(st, tr_off(offA[i], row0)), lds_tr_read(st, tr_off(offA[i], row0 + 4)));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = join4(lds_tr_read(st, tr_off(offB[j], row0)), lds_tr_read(st, tr_off(offB[j], row0 + 4)));
+            for (int j = 0; j < NJ; ++j) bf[j] = join4(lds_tr_read(st, tr_off(offB[j], row0)), lds_tr_read(st, tr_off(offB[j], row0 + 4)));
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma32(af[i], bf[j], acc[i][j]);
         }
         if (do_bias && (SWAP || (kt % tiles_q) == tq) && brg < BRG) {
             const int im = (SWAP ? 3 : 0) + (bch >> 4), ci = bch & 15;
@@ -1473,8 +1477,8 @@ __device__ __forceinline__ void tn384w_body(const GemmTnArgs& a, int bid, char* 
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = q0 + wq * 128 + j * 32 + r32;
+        for (int j = 0; j < NJ; ++j) {
+            const int q = q0 + wq * 32 * NJ + j * 32 + r32;
             if constexpr (SWAP) {  // caller's layout: row q (its P index), column p (its Q index, a.P of them); registers 4g .. 4g + 3 = four consecutive p
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1547,8 +1551,9 @@ __global__ __launch_bounds__(512) void gemm_tn384_group_kernel(GemmTnGroup g) {
     while (i + 1 < g.n && id >= g.start[i + 1]) ++i;
     const GemmTnArgs a = g.d[i];
 #if DCV_TN_WIDE_Q
-    if (a.mode == 1) return tn384w_body<false>(a, id - g.start[i], smem);
-    if (a.mode == 2) return tn384w_body<true>(a, id - g.start[i], smem);
+    if constexpr ((DCV_TN_WIDE_Q & 1) != 0) { if (a.mode == 1) return tn384w_body<false>(a, id - g.start[i], smem); }
+    if constexpr ((DCV_TN_WIDE_Q & 2) != 0) { if (a.mode == 2) return tn384w_body<true>(a, id - g.start[i], smem); }
+    if constexpr ((DCV_TN_WIDE_Q & 4) != 0) { if (a.mode == 3) return tn384w_body<false, 3>(a, id - g.start[i], smem); }
 #endif
     tn384_body(a, id - g.start[i], smem);
 }
@@ -1799,13 +1804,17 @@ struct TnGroupPlan {
 static int tn_group_plan(const dcv_tn_item* it, int n, int M, int cus, TnGroupPlan& pl) {
     if (!it) return DCV_ERR_NULL;
     if (n < 1 || n > TN_GROUP_MAX || M <= 0) return DCV_ERR_SHAPE;
-    int units = 0;
+    int units = 0;  // in half tiles of 384 x 128
+    static const int weight[4] = {2, 4, 4, 3}, tile_q[4] = {128, 256, 0, 192};
     for (int i = 0; i < n; ++i) {
         if (!it[i].Y || !it[i].X || !it[i].dW) return DCV_ERR_NULL;
         if (it[i].P <= 0 || it[i].Q <= 0 || (it[i].P % 384) || (it[i].Q % 128)) return DCV_ERR_UNSUPPORTED;
         if ((it[i].ldy % 8) || (it[i].ldx % 8) || ((uintptr_t)it[i].Y & 15) || ((uintptr_t)it[i].X & 15)) return DCV_ERR_ALIGN;
         const int P = it[i].P, Q = it[i].Q;
-        if ((DCV_TN_WIDE_Q & 1) && (Q % 256) == 0) {
+        if ((DCV_TN_WIDE_Q & 4) && (Q % 192) == 0) {
+            pl.mode[i] = 3;
+            pl.tiles[i] = (P / 384) * (Q / 192);
+        } else if ((DCV_TN_WIDE_Q & 1) && (Q % 256) == 0) {
             pl.mode[i] = 1;
             pl.tiles[i] = (P / 384) * (Q / 256);
         } else if ((DCV_TN_WIDE_Q & 2) && (Q % 384) == 0 && (P % 256) == 0) {
@@ -1815,21 +1824,22 @@ static int tn_group_plan(const dcv_tn_item* it, int n, int M, int cus, TnGroupPl
             pl.mode[i] = 0;
             pl.tiles[i] = (P / 384) * (Q / 128);
         }
-        units += pl.tiles[i] * (pl.mode[i] ? 2 : 1);
+        units += pl.tiles[i] * weight[pl.mode[i]];
     }
-    if (units > cus) return DCV_ERR_UNSUPPORTED;  // more than one resident round: call the products one by one
-    const int base = cus / units;
+    if (units > 2 * cus) return DCV_ERR_UNSUPPORTED;  // more than one resident round: call the products one by one
+    const int base2 = 2 * cus / units;  // splits of a 384 x 128 product
     const int max3 = (M + T3_BK - 1) / T3_BK;
     pl.need = 0;
     for (int i = 0; i < n; ++i) {
-        int sp = base * (pl.mode[i] ? 2 : 1);
+        int sp = base2 * weight[pl.mode[i]] / 2;
+        if (sp < 1) sp = 1;
         if (sp > max3) sp = max3;
         const int mps = ((M + sp - 1) / sp + T3_BK - 1) / T3_BK * T3_BK;
         pl.mps[i] = mps;
         pl.splits[i] = (M + mps - 1) / mps;
         // per item: [splits][P * Q] partial tiles (the caller's layout), then the bias partials: [splits * tiles_q][P], or [splits][P] for the transposed form
         pl.off[i] = pl.need;
-        const int bias_rows = pl.mode[i] == 2 ? pl.splits[i] : pl.splits[i] * (it[i].Q / (pl.mode[i] == 1 ? 256 : 128));
+        const int bias_rows = pl.mode[i] == 2 ? pl.splits[i] : pl.splits[i] * (it[i].Q / tile_q[pl.mode[i]]);
         pl.need += (long)pl.splits[i] * it[i].P * it[i].Q + (long)bias_rows * it[i].P;
     }
     return DCV_OK;
@@ -1881,7 +1891,7 @@ extern "C" int dcv_gemm_tn_group(const dcv_tn_item* items, int n, int M, float* 
             const long stride = (long)t.P * t.Q;
             float* w = ws + pl.off[i];
             if (!det_jobs_add(jb, w, pl.splits[i], stride, t.dW, stride, t.Q, t.lddw)) return DCV_ERR_ALIGN;
-            const int bias_rows = pl.mode[i] == 2 ? pl.splits[i] : pl.splits[i] * (t.Q / (pl.mode[i] == 1 ? 256 : 128));
+            const int bias_rows = pl.mode[i] == 2 ? pl.splits[i] : pl.splits[i] * (t.Q / (pl.mode[i] == 1 ? 256 : pl.mode[i] == 3 ? 192 : 128));
             if (t.dbias && !det_jobs_add(jb, w + stride * pl.splits[i], bias_rows, t.P, t.dbias, t.P, t.P, t.P)) return DCV_ERR_ALIGN;
         }
         if (!det_reduce_multi(jb, (hipStream_t)stream)) return DCV_ERR_LAUNCH;
