@@ -43,14 +43,7 @@ __global__ __launch_bounds__(256) void attn_fwd3_kernel(AttnArgs a) {
     const int nqt = (a.Nq + 127) / 128;
     const int BH = a.B * a.H;
     int bh, qt;
-    if ((BH & 7) == 0) {
-        int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        bh = (slot / nqt) * 8 + xcd;
-        qt = slot % nqt;
-    } else {
-        bh = blockIdx.x / nqt;
-        qt = blockIdx.x % nqt;
-    }
+    attn_block_to_tile(blockIdx.x, BH, nqt, a.Nq, bh, qt);
     const int b = bh / a.H, hh = bh % a.H;
     const int D = a.H * 64;
     const size_t rs = (size_t)3 * D;

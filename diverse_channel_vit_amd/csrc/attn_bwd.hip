@@ -56,14 +56,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq2_kernel(AttnArgs a) {
     const int nqt = (a.N - a.key_lo + 127) / 128;  // query tiles launched: rows [key_lo, N); those beyond Nq only clear their dQ rows (dqkv is fully defined)
     const int BH = a.B * a.H;
     int bh, qt;
-    if ((BH & 7) == 0) {
-        int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        bh = (slot / nqt) * 8 + xcd;
-        qt = slot % nqt;
-    } else {
-        bh = blockIdx.x / nqt;
-        qt = blockIdx.x % nqt;
-    }
+    attn_block_to_tile(blockIdx.x, BH, nqt, a.Nq == a.N ? a.N - a.key_lo : 0, bh, qt);
     qt += a.key_lo / 128;
     const int b = bh / a.H, hh = bh % a.H;
     const int D = a.H * 64;

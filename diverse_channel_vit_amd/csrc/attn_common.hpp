@@ -35,6 +35,31 @@ struct AttnArgs {
     int key_lo = 0, key_hi = 0;  // dK / dV kernels launched for a key range only: keys [key_lo, key_hi) (0, 0: all)
 };
 
+// blockIdx -> (batch-head, 128-query tile) of the forward and dQ kernels.  An XCD gets all tiles of a batch-head (its K / V stay in that XCD's L2).
+// DCV_ATTN_LIGHT_LAST (variant builds): when the last query tile is ragged (N = 1569: 33 of 128 rows, two of its four waves idle), those light workgroups
+// are numbered AFTER all full ones, so that the full tiles fill whole rounds of resident workgroups and the light ones share the tail round.  Measured: no
+// change (forward 300 -> 306 us, dQ 385 -> 380, inside the run-to-run spread; profiles/r05_x8_* (c)); off in the product.
+#ifndef DCV_ATTN_LIGHT_LAST
+#define DCV_ATTN_LIGHT_LAST 0
+#endif
+__device__ __forceinline__ void attn_block_to_tile(int bid, int BH, int nqt, int n_rows, int& bh, int& qt) {
+    if ((BH & 7) != 0) {
+        bh = bid / nqt;
+        qt = bid % nqt;
+        return;
+    }
+    const bool light = DCV_ATTN_LIGHT_LAST && (n_rows & 127) != 0 && (n_rows & 127) <= 64 && nqt > 1;
+    const int nf = light ? nqt - 1 : nqt;
+    if (bid < BH * nf) {
+        const int xcd = bid & 7, slot = bid >> 3;
+        bh = (slot / nf) * 8 + xcd;
+        qt = slot % nf;
+    } else {
+        bh = bid - BH * nf;  // (bh & 7 = the XCD of its full tiles)
+        qt = nqt - 1;
+    }
+}
+
 // stage a [64 rows][64 cols] bf16 tile: 512 chunks of 16 B, 256 threads x 2
 struct Stage64 {
     uint4 r[2];
