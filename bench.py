@@ -592,8 +592,9 @@ def main():
             fallback = build_line(r[0], r[1], r[2], r[3].item(), mode)
     chosen_mode, (dt, med_ms, live, loss) = best
     final_loss = loss.item()
-    line = build_line(dt, med_ms, live, final_loss, chosen_mode)
-    line["status"] = "ok"
+    line = build_line(dt, med_ms, live, final_loss, chosen_mode)  # None on every rank but 0
+    if line is not None:
+        line["status"] = "ok"
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()

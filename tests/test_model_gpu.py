@@ -717,6 +717,34 @@ def test_dp_reducer_on_rccl_single_gpu(gpu_device):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_as_the_driver_launches_it(gpu_device):
+    """`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2` — the driver's N > 1 command line — end to end on this box's one GPU
+    (DCV_BENCH_REHEARSAL=gloo: both ranks on cuda:0, gloo instead of RCCL, which refuses two ranks on one device).  Every rank must leave with exit code 0
+    and rank 0 must print exactly ONE JSON line with both exchange modes timed.  Regression: round 5's `status` field was written on the ranks that have no
+    line (rank != 0 raised TypeError after the timed region and the launcher tore the job down) — no single-process test executes those branches."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DCV_BENCH_REHEARSAL="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["status"] == "ok" and line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["dp"]["world_size"] == 2 and set(line["dp"]["modes"]) == {"single_allreduce_after_backward", "overlap"}
+    assert line["value"] > 0 and abs(line["value"] - 16 * 2 / (line["ms_per_step"] / 1e3)) <= 0.02 * line["value"]  # whole-job images per second
+    print(f"two ranks on one GPU over gloo: {line['value']:.0f} img/s, modes {line['dp']['modes']}")
+
+
 def test_base_width_train_step(gpu_device):
     """DiChaViT-Base dimensions (D = 768, 12 heads, MLP 3072; BASELINE config 5's architecture) on a small image:
     one training step against the oracle — exercises every kernel at the wider layout (LN/ortho lanes, GEMM N tiles
