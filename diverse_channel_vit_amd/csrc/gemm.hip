@@ -1025,6 +1025,176 @@ __global__ __launch_bounds__(512) void gemm_nt384_kernel(GemmNtArgs a) {
     }
 }
 
+#ifndef DCV_NT_ALT
+#define DCV_NT_ALT 0
+#endif
+#if DCV_NT_ALT
+// ------------------------------------------------------------------------------------------------
+// gemm_nt_alt (round 5, DCV_TILE_ALT; variant builds with -DDCV_NT_ALT=1 only — measured 15-27 % SLOWER than the best shipped tile on every shape,
+// profiles/r05_x9_*): the 256 x 384 kernel's eight waves as TWO groups of four (one wave of either group on every SIMD) that work on the
+// two 192-column halves of a tile in ALTERNATING phases: while group 0 runs the k-loop of its half (the matrix pipe), group 1 runs the epilogue of the half it
+// accumulated one phase earlier (vector arithmetic, auxiliary loads, stores), then they swap.  The LDS ring belongs to whichever group is in its k-loop — two
+// stages of (256 + 192) rows x 128 B = 112 KB — so, unlike two co-resident workgroups (gemm_nt_pair: 128 x 128 tiles), the wave tile stays 64 x 192.  A phase is
+// K / 64 slots; every slot opens with the workgroup barrier (the k-loop group needs it per stage, the other group just arrives), the epilogue group spreads its
+// six chunks (2 row blocks x one 64-column group each) over the slots and issues the first stage of ITS next half into the free buffer during the last slot.
+// Cost: the A panel is pulled into LDS once per half (3840 -> 5376 lines per tile at K = 384).  bf16-output epilogues only.
+constexpr int NA_A_BYTES = 256 * 128, NA_W_BYTES = 192 * 128, NA_STAGE_BYTES = NA_A_BYTES + NA_W_BYTES, NA_SMEM = 2 * NA_STAGE_BYTES;  // 56 KB stages, 112 KB
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_alt_kernel(GemmNtArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[NA_SMEM];
+    static_assert(!epi_f32out<EPI>() && EPI != DCV_EPI_RESID_LN, "bf16-output epilogues only");
+    constexpr bool HAS_BIAS = (EPI != DCV_EPI_PLAIN_BF16) && (EPI != DCV_EPI_GELU_BWD_BF16);
+    constexpr bool HAS_AUX = (EPI == DCV_EPI_GELU_BWD_BF16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wm = wave & 3;  // waves w and w + 4 share a SIMD: one of either group
+    const int tiles_n = a.N / N3_BN;
+    const int tiles_m = (a.M + N3_BM - 1) / N3_BM;
+    const int total = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    const int pos = ((G & 7) == 0) ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    if (pos >= total) return;
+    const int n_mine = (total - pos + G - 1) / G;  // tiles this workgroup walks: pos, pos + G, ...
+
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const unsigned dmaA = 64 * wm * 128, dmaW = NA_A_BYTES + 48 * wm * 128;  // per stage a k-loop wave brings A rows [64 wm, +64) = 8 pieces, W rows [48 wm, +48) = 6
+    const int nk = a.K / N3_BK;
+    const int r16 = lane & 15, kg = lane >> 4;
+    int fA0, fA1, fW0, fW1;
+    {
+        const int rowA = (wm * 64 + r16) * 128, rowW = NA_A_BYTES + r16 * 128;
+        const int co0 = (kg ^ swz64n(r16)) << 4;
+        fA0 = rowA + co0; fA1 = rowA + (co0 ^ 64); fW0 = rowW + co0; fW1 = rowW + (co0 ^ 64);
+        asm volatile("" : "+v"(fA0), "+v"(fA1), "+v"(fW0), "+v"(fW1));
+    }
+    unsigned voffA[2], voffW[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rowa = 64 * wm + 8 * q + (lane >> 3), roww = 48 * wm + 8 * q + (lane >> 3);
+        voffA[q] = (unsigned)(((size_t)rowa * a.lda + (((lane & 7) ^ swz64n(rowa)) * 8)) * 2);
+        voffW[q] = (unsigned)(((size_t)roww * a.ldw + (((lane & 7) ^ swz64n(roww)) * 8)) * 2);
+    }
+    // stage kt of the half (tile L, column half grp) into the buffer at stage_base
+    auto issue = [&](int L, int kt, unsigned stage_base) {
+        const int m0 = __builtin_amdgcn_readfirstlane((L / tiles_n) * N3_BM), n0 = __builtin_amdgcn_readfirstlane((L % tiles_n) * N3_BN + 192 * grp);
+        const bf16_t* ab = a.A + (size_t)m0 * a.lda + kt * N3_BK;
+        const bf16_t* wb = a.W + (size_t)n0 * a.ldw + kt * N3_BK;
+        if (m0 + N3_BM <= a.M) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) glds16s(ab + (size_t)(q >> 1) * 16 * a.lda, voffA[q & 1], stage_base + dmaA + q * 1024);
+        } else {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = 64 * wm + 8 * q + (ln >> 3);
+                const int rc = min(m0 + row, a.M - 1) - m0;
+                glds16s(ab, (unsigned)(((size_t)rc * a.lda + (((ln & 7) ^ swz64n(row)) * 8)) * 2), stage_base + dmaA + q * 1024);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) glds16s(wb + (size_t)(q >> 1) * 16 * a.ldw, voffW[q & 1], stage_base + dmaW + q * 1024);
+    };
+
+    int g = 0;  // slot counter of the workgroup: the k-loop group's stage of slot g lives in buffer g & 1
+    // a phase in which this group has nothing in its accumulators: arrive at every slot's barrier; with_issue: my first stage goes out in the last slot
+    auto idle_phase = [&](bool with_issue) {
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            __builtin_amdgcn_s_barrier();
+            if (with_issue && kt == nk - 1) issue(pos, 0, smem_base + ((g + 1) & 1) * NA_STAGE_BYTES);
+        }
+    };
+    // group 0: k e k e ... k e idle;  group 1: idle k e ... k e — in every phase one group owns the ring and the matrix pipe, the other stores.  The loop body is
+    // straight-line (k-loop, then epilogue): the accumulators are defined and dead inside one iteration (as a branch per phase they became loop-carried values
+    // the register allocator spilled)
+    if (grp == 0) issue(pos, 0, smem_base);
+    else idle_phase(true);
+
+    for (int t = 0; t < n_mine; ++t) {
+        const int L = pos + t * G;
+        f32x4 acc[4][12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+#pragma clang loop unroll(disable)
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of stage kt (and, for kt == 0, my last epilogue's stores)
+            __builtin_amdgcn_s_barrier();
+            const char* st = smem + (g & 1) * NA_STAGE_BYTES;
+            const char* const pA0 = st + fA0;
+            const char* const pA1 = st + fA1;
+            const char* const pW0 = st + fW0;
+            const char* const pW1 = st + fW1;
+            auto rdW = [&](int s2) { return as_bf16x8(lds_read128(s2 >= 12 ? pW1 : pW0, (s2 % 12) * 16 * 128)); };
+            bf16x8 af[4], wq[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = as_bf16x8(lds_read128(pA0, i * 16 * 128));
+            wq[0] = rdW(0);
+            wq[1] = rdW(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) issue(L, kt + 1, smem_base + ((g + 1) & 1) * NA_STAGE_BYTES);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < 24; ++s2) {
+                if (s2 + 2 < 24) wq[(s2 + 2) % 3] = rdW(s2 + 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][s2 % 12] = mfma16(wq[s2 % 3], af[i], acc[i][s2 % 12]);
+                    if (s2 == 11) af[i] = as_bf16x8(lds_read128(pA1, i * 16 * 128));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue phase: six chunks (one 64-column group x two 16-row blocks each) spread over the slots; my next first stage in the last slot ----
+        const int m_w = (L / tiles_n) * N3_BM + wm * 64, n_w = (L % tiles_n) * N3_BN + 192 * grp;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int r16e = ln & 15, kge = ln >> 4;
+        const int rr = r16e & 7, cl = 32 * (r16e >> 3) + 16 * (kge & 1) + 8 * (kge >> 1);
+        const bool more = t + 1 < n_mine;
+        // chunk ch runs in slot ch * nk / 6; the sequence over the chunks is straight-line (the accumulators of a chunk die with it), the slots between them
+        // are opened by a counted loop of barriers
+        int kt = 0;
+        auto open_slots = [&](int upto) {  // open slots kt .. upto (inclusive)
+            for (; kt <= upto; ++kt, ++g) {
+                __builtin_amdgcn_s_barrier();
+                if (more && kt == nk - 1) issue(L + G, 0, smem_base + ((g + 1) & 1) * NA_STAGE_BYTES);  // free since the barrier above
+            }
+        };
+#pragma unroll
+        for (int ch = 0; ch < 6; ++ch) {
+            open_slots(ch * nk / 6);
+            const int c = ch >> 1;
+            float bz[8];
+            if constexpr (HAS_BIAS) nt_load_bias<EPI, 4>(a, n_w + 64 * c, r16e, kge, bz);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * (ch & 1) + ii;
+                float x[2][8];
+                if constexpr (HAS_AUX) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) epi_aux8<EPI>(a, min(m_w + 16 * i + 8 * h + rr, a.M - 1), min(n_w + 64 * c + cl, a.N - 8), x[h]);
+                }
+                float v0[8], v1[8], va[8], vb[8];
+                swap_pair8(acc[i][4 * c], acc[i][4 * c + 1], v0);
+                swap_pair8(acc[i][4 * c + 2], acc[i][4 * c + 3], v1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xchg_rows8(v0[e], v1[e], va[e], vb[e]);
+                const int m = m_w + 16 * i + rr, n = n_w + 64 * c + cl;
+                if (m < a.M && n < a.N) epi_store8<EPI>(a, m, n, va, x[0], bz);
+                if (m + 8 < a.M && n < a.N) epi_store8<EPI>(a, m + 8, n, vb, x[1], bz);
+            }
+        }
+        open_slots(nk - 1);
+    }
+    if (grp == 0) idle_phase(false);
+}
+#endif  // DCV_NT_ALT
+
 // ------------------------------------------------------------------------------------------------
 struct GemmTnArgs {
     const bf16_t* Y;
@@ -1598,9 +1768,10 @@ static int dcv_cu_count() {
 
 // which kernel dcv_gemm_nt_ex launches for this problem (DCV_TILE_NARROW / DCV_TILE_WIDE), or a negative error for an illegal forced tile
 extern "C" int dcv_gemm_nt_pick(int M, int N, int K, int epilogue, int tile) {
-    if (tile < DCV_TILE_AUTO || tile > DCV_TILE_PAIR) return DCV_ERR_SHAPE;
+    if (tile < DCV_TILE_AUTO || tile > DCV_TILE_ALT) return DCV_ERR_SHAPE;
     const bool legal384 = (N % N3_BN) == 0 && epilogue != DCV_EPI_PATCH;
     if (tile == DCV_TILE_WIDE) return legal384 ? DCV_TILE_WIDE : DCV_ERR_UNSUPPORTED;
+    if (tile == DCV_TILE_ALT) return (DCV_NT_ALT && legal384 && epilogue != DCV_EPI_BIAS_RESID_F32) ? DCV_TILE_ALT : DCV_ERR_UNSUPPORTED;
     if (tile == DCV_TILE_NARROW) return DCV_TILE_NARROW;
     if (tile == DCV_TILE_PAIR) return epilogue != DCV_EPI_PATCH ? DCV_TILE_PAIR : DCV_ERR_UNSUPPORTED;
 #ifndef DCV_WIDE_K_MIN
@@ -1633,7 +1804,7 @@ extern "C" int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, in
     if (!A || !W || !out) return DCV_ERR_NULL;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 8) != 0) return DCV_ERR_SHAPE;
     if ((lda % 8) || (ldw % 8) || (ldo % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return DCV_ERR_ALIGN;
-    if (grid_cap < 0 || tile < DCV_TILE_AUTO || tile > DCV_TILE_PAIR) return DCV_ERR_SHAPE;
+    if (grid_cap < 0 || tile < DCV_TILE_AUTO || tile > DCV_TILE_ALT) return DCV_ERR_SHAPE;
     if (epilogue == DCV_EPI_BIAS_RESID_F32 && aux2 && (T <= 0 || (M % T) != 0)) return DCV_ERR_SHAPE;  // per-sample branch scale: T rows per sample
     // persistent kernels: one workgroup per CU walks the tiles; grid_cap (> 0) lowers the number of workgroups — the data-parallel
     // backward leaves CUs to RCCL's kernels this way (dichavit.py), tests force multi-round walks on small problems
@@ -1656,6 +1827,33 @@ extern "C" int dcv_gemm_nt_ex(const void* A, int lda, const void* W, int ldw, in
         DCV_LAUNCH_CHECK();
         return DCV_OK;
     }
+#if DCV_NT_ALT
+    if (pick == DCV_TILE_ALT) {
+        int ga = ((M + N3_BM - 1) / N3_BM) * (N / N3_BN);
+        if (ga > cap) ga = cap;
+        switch (epilogue) {
+            case DCV_EPI_BIAS_BF16:
+                if (!bias) return DCV_ERR_NULL;
+                hipLaunchKernelGGL(gemm_nt_alt_kernel<DCV_EPI_BIAS_BF16>, dim3(ga), dim3(512), 0, s, a);
+                break;
+            case DCV_EPI_BIAS_GELU_BF16:
+                if (!bias || !out2) return DCV_ERR_NULL;
+                hipLaunchKernelGGL(gemm_nt_alt_kernel<DCV_EPI_BIAS_GELU_BF16>, dim3(ga), dim3(512), 0, s, a);
+                break;
+            case DCV_EPI_PLAIN_BF16:
+                hipLaunchKernelGGL(gemm_nt_alt_kernel<DCV_EPI_PLAIN_BF16>, dim3(ga), dim3(512), 0, s, a);
+                break;
+            case DCV_EPI_GELU_BWD_BF16:
+                if (!aux) return DCV_ERR_NULL;
+                hipLaunchKernelGGL(gemm_nt_alt_kernel<DCV_EPI_GELU_BWD_BF16>, dim3(ga), dim3(512), 0, s, a);
+                break;
+            default:
+                return DCV_ERR_UNSUPPORTED;
+        }
+        DCV_LAUNCH_CHECK();
+        return DCV_OK;
+    }
+#endif
     if (pick == DCV_TILE_PAIR) {
         int gp = ((M + NP_BM - 1) / NP_BM) * ((N + NP_BN - 1) / NP_BN);
         if (gp > 2 * cap) gp = 2 * cap;  // two workgroups per CU

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCV_LIB", os.path.join(_HERE, "libdcv_hip.so"))  # DCV_LIB: A/B builds of the same ABI
 
 EPI_BIAS_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_RESID_F32, EPI_PLAIN_BF16, EPI_GELU_BWD_BF16, EPI_PATCH = range(6)
-TILE_AUTO, TILE_NARROW, TILE_WIDE, TILE_PAIR = range(4)  # include/dcv.h DCV_TILE_*
+TILE_AUTO, TILE_NARROW, TILE_WIDE, TILE_PAIR, TILE_ALT = range(5)  # include/dcv.h DCV_TILE_*
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 _SIGS = {
@@ -229,7 +229,7 @@ def gemm_nt(A, W, epilogue, out, *, bias=None, out2=None, aux=None, aux2=None, T
     lib = load()
 
     def describe():
-        kind = {TILE_WIDE: "gemm_nt384", TILE_PAIR: "gemm_nt_pair"}.get(lib.dcv_gemm_nt_pick(M, N, K, epilogue, tile), "gemm_nt")
+        kind = {TILE_WIDE: "gemm_nt384", TILE_PAIR: "gemm_nt_pair", TILE_ALT: "gemm_nt_alt"}.get(lib.dcv_gemm_nt_pick(M, N, K, epilogue, tile), "gemm_nt")
         nbytes = 2.0 * M * K + 2.0 * N * K + M * N * (_EPI_OUT_BYTES[epilogue] + _EPI_AUX_BYTES[epilogue])
         return f"{kind}_kernel<{epilogue}>", f"M{M} N{N} K{K}", 2.0 * M * N * K, None, nbytes
 

@@ -52,6 +52,7 @@ int dcv_gemm_nt(const void* A, int lda, const void* W, int ldw, int M, int N, in
 #define DCV_TILE_NARROW 1
 #define DCV_TILE_WIDE 2
 #define DCV_TILE_PAIR 3 /* dcv_gemm_nt_ex only: 128 x 128 tiles by four-wave workgroups, TWO per CU (one stores while the other computes) */
+#define DCV_TILE_ALT 4  /* dcv_gemm_nt_ex only: 256 x 384 tiles whose two 192-column halves are accumulated and stored in alternating phases by the two wave groups of a workgroup (bf16-output epilogues, N % 384 == 0); compiled into variant builds only (-DDCV_NT_ALT=1: measured slower), DCV_ERR_UNSUPPORTED otherwise */
 /* dcv_gemm_nt with its launch controls as arguments: both kernels are persistent (one workgroup per CU walks the output
  * tiles, several rounds when there are more tiles than workgroups); grid_cap > 0 caps the number of workgroups (0 = one per
  * CU of the current device) — the data-parallel backward leaves CUs to RCCL's kernels this way. */

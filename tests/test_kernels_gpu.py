@@ -38,8 +38,8 @@ def _close(a, b, rtol, atol, what=""):
 GEMM_SHAPES = [(300, 384, 384), (128, 128, 64), (777, 1152, 384), (1000, 384, 1536), (257, 192, 192), (130, 576, 192)]
 
 
-def _check_gemm_nt(hip, M, N, K, **kw):
-    """All five Linear epilogues of dcv_gemm_nt_ex against fp32 torch.matmul on the same bf16 operands."""
+def _check_gemm_nt(hip, M, N, K, resid=True, **kw):
+    """All five Linear epilogues of dcv_gemm_nt_ex against fp32 torch.matmul on the same bf16 operands (resid=False: the four bf16-output ones)."""
     A, W = _bf(M, K, seed=1), _bf(N, K, scale=0.05, seed=2)
     bias = _f(N, scale=0.1, seed=3)
     ref = A.float() @ W.float().t()
@@ -59,16 +59,17 @@ def _check_gemm_nt(hip, M, N, K, **kw):
     _close(h, hr.detach(), 1e-2, 2e-2, "gelu h")
     _close(out, zr.grad, 1e-2, 2e-2, "gelu'")
     del hr, zr
-    # residual f32 in place
-    x = _f(M, N, seed=4)
-    x0 = x.clone()
-    hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, x, bias=bias, **kw)
-    _close(x, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32")
-    y = torch.empty_like(x)
-    hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, y, bias=bias, aux=x0, **kw)  # out-of-place residual
-    _close(y, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32 out-of-place")
-    assert torch.equal(y, x)
-    del x, y, x0
+    if resid:
+        # residual f32 in place
+        x = _f(M, N, seed=4)
+        x0 = x.clone()
+        hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, x, bias=bias, **kw)
+        _close(x, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32")
+        y = torch.empty_like(x)
+        hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, y, bias=bias, aux=x0, **kw)  # out-of-place residual
+        _close(y, x0 + ref + bias, 1e-4, 2e-4 * math.sqrt(K), "resid_f32 out-of-place")
+        assert torch.equal(y, x)
+        del x, y, x0
     # gelu backward epilogue: acc * saved GELU'
     gp = _bf(M, N, seed=5)
     hip.gemm_nt(A, W, hip.EPI_GELU_BWD_BF16, out, aux=gp, **kw)
@@ -123,6 +124,22 @@ def test_gemm_nt_384_wide_tiles(hip, M, N, K):
     """The 256 x 384 tile kernel (gemm_nt384, used for N % 384 == 0 where it pays) on every epilogue it carries, forced with
     tile=TILE_WIDE: full tiles, a partial last M tile, one and several k-stages, 1 / 3 / 4 column tiles."""
     _check_gemm_nt(hip, M, N, K, tile=hip.TILE_WIDE)
+
+
+@pytest.mark.parametrize("grid_cap", [0, 3])
+@pytest.mark.parametrize("M,N,K", [(4100, 1152, 384), (4352, 384, 1536), (4608, 1536, 384), (5000, 384, 64), (300, 384, 128), (9000, 768, 320),
+                                   (64 * 1569, 1536, 384)])
+def test_gemm_nt_alternating_halves(hip, M, N, K, grid_cap):
+    """gemm_nt_alt (TILE_ALT; variant builds only — skipped on the product library): the two wave groups of a workgroup accumulate and store the two 192-column halves of a 256 x 384 tile in alternating
+    phases on one shared LDS ring — every bf16-output epilogue, one to 24 k-stages per phase (fewer and more slots than the six epilogue chunks), a partial last
+    M tile, one tile per workgroup and long walks under a grid cap (an odd number of tiles per workgroup included), the headline fc1 shape; the fp32 residual
+    epilogue is refused."""
+    if hip.load().dcv_gemm_nt_pick(M, N, K, hip.EPI_PLAIN_BF16, hip.TILE_ALT) != hip.TILE_ALT:
+        pytest.skip("gemm_nt_alt is compiled into variant builds only (-DDCV_NT_ALT=1: measured slower than the shipped tiles, profiles/r05_x9_*)")
+    _check_gemm_nt(hip, M, N, K, resid=False, tile=hip.TILE_ALT, grid_cap=grid_cap)
+    A, W = _bf(256, K, seed=1), _bf(N, K, seed=2)
+    with pytest.raises(RuntimeError):
+        hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, torch.zeros(256, N, device="cuda"), bias=_f(N, seed=3), tile=hip.TILE_ALT)
 
 
 # The headline step's GEMMs: M = 64 x 1569 = 100 416 token rows.  Both NT kernels are PERSISTENT: one workgroup per CU walks

@@ -16,7 +16,7 @@ cases = [("qkv        N1152 K384  bias", A, 3 * D, hip.EPI_BIAS_BF16), ("fc1    
          ("gelu-bwd   N1536 K384", A, 4 * D, hip.EPI_GELU_BWD_BF16), ("dgrad fc1T N384  K1536 plain", A4, D, hip.EPI_PLAIN_BF16),
          ("dgrad qkvT N384  K1152 plain", A3, D, hip.EPI_PLAIN_BF16), ("dgrad proj N384  K384  plain", A, D, hip.EPI_PLAIN_BF16),
          ("fc2        N384  K1536 bias+resid", A4, D, hip.EPI_BIAS_RESID_F32), ("proj       N384  K384  bias+resid", A, D, hip.EPI_BIAS_RESID_F32)]
-names = {hip.TILE_NARROW: "narrow", hip.TILE_WIDE: "wide", hip.TILE_PAIR: "pair"}
+names = {hip.TILE_NARROW: "narrow", hip.TILE_WIDE: "wide", hip.TILE_PAIR: "pair", hip.TILE_ALT: "alt"}
 rounds = int(os.environ.get("GB_ROUNDS", 12))
 for name, a, N, epi in cases:
     K = a.shape[1]
