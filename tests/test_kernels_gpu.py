@@ -126,20 +126,19 @@ def test_gemm_nt_384_wide_tiles(hip, M, N, K):
     _check_gemm_nt(hip, M, N, K, tile=hip.TILE_WIDE)
 
 
-@pytest.mark.parametrize("grid_cap", [0, 3])
-@pytest.mark.parametrize("M,N,K", [(4100, 1152, 384), (4352, 384, 1536), (4608, 1536, 384), (5000, 384, 64), (300, 384, 128), (9000, 768, 320),
-                                   (64 * 1569, 1536, 384)])
-def test_gemm_nt_alternating_halves(hip, M, N, K, grid_cap):
-    """gemm_nt_alt (TILE_ALT; variant builds only — skipped on the product library): the two wave groups of a workgroup accumulate and store the two 192-column halves of a 256 x 384 tile in alternating
-    phases on one shared LDS ring — every bf16-output epilogue, one to 24 k-stages per phase (fewer and more slots than the six epilogue chunks), a partial last
-    M tile, one tile per workgroup and long walks under a grid cap (an odd number of tiles per workgroup included), the headline fc1 shape; the fp32 residual
-    epilogue is refused."""
-    if hip.load().dcv_gemm_nt_pick(M, N, K, hip.EPI_PLAIN_BF16, hip.TILE_ALT) != hip.TILE_ALT:
+def test_gemm_nt_alternating_halves(hip):
+    """gemm_nt_alt (TILE_ALT; variant builds only — ONE skip on the product library): the two wave groups of a workgroup accumulate and store the two 192-column
+    halves of a 256 x 384 tile in alternating phases on one shared LDS ring — every bf16-output epilogue, one to 24 k-stages per phase (fewer and more slots than the
+    six epilogue chunks), a partial last M tile, one tile per workgroup and long walks under a grid cap (an odd number of tiles per workgroup included), the headline
+    fc1 shape; the fp32 residual epilogue is refused."""
+    if hip.load().dcv_gemm_nt_pick(4100, 1152, 384, hip.EPI_PLAIN_BF16, hip.TILE_ALT) != hip.TILE_ALT:
         pytest.skip("gemm_nt_alt is compiled into variant builds only (-DDCV_NT_ALT=1: measured slower than the shipped tiles, profiles/r05_x9_*)")
-    _check_gemm_nt(hip, M, N, K, resid=False, tile=hip.TILE_ALT, grid_cap=grid_cap)
-    A, W = _bf(256, K, seed=1), _bf(N, K, seed=2)
+    for M, N, K in [(4100, 1152, 384), (4352, 384, 1536), (4608, 1536, 384), (5000, 384, 64), (300, 384, 128), (9000, 768, 320), (64 * 1569, 1536, 384)]:
+        for grid_cap in (0, 3):
+            _check_gemm_nt(hip, M, N, K, resid=False, tile=hip.TILE_ALT, grid_cap=grid_cap)
+    A, W = _bf(256, 384, seed=1), _bf(384, 384, seed=2)
     with pytest.raises(RuntimeError):
-        hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, torch.zeros(256, N, device="cuda"), bias=_f(N, seed=3), tile=hip.TILE_ALT)
+        hip.gemm_nt(A, W, hip.EPI_BIAS_RESID_F32, torch.zeros(256, 384, device="cuda"), bias=_f(384, seed=3), tile=hip.TILE_ALT)
 
 
 # The headline step's GEMMs: M = 64 x 1569 = 100 416 token rows.  Both NT kernels are PERSISTENT: one workgroup per CU walks
